@@ -1,0 +1,195 @@
+/*
+ * vgpa.h -- C ABI of libvgpa_hip.so: the gfx950 (MI355X) kernels behind the
+ * variational free-energy / gradient evaluation of VGPA.
+ *
+ * Conventions
+ *   - Every array is float64 (or int32 where stated), C order, contiguous, in
+ *     DEVICE memory owned by the caller.  The leading axis P is the batch of
+ *     independent problems (grid points, restarts); P = 1 for one problem.
+ *   - D is the state dimension.  For D == 1 the trailing D / DxD axes are
+ *     dropped: A, b, m, S, ... are (P, N).
+ *   - A "stride" argument is the element distance between consecutive
+ *     problems of a parameter array; 0 means the same values are shared by all
+ *     P problems.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue
+ *     work; they never synchronise, allocate or free device memory.
+ *   - Return value: 0 on success, a negative VGPA_E* code otherwise; the text
+ *     of the last error of the calling thread is vgpa_last_error_string().
+ *   - Integration methods follow the reference's four ODE schemes.
+ *
+ * Citations are to the reference implementation (ruiixu23/VGPA), paths relative
+ * to its root; core/likelihood.py is cited with virtual line numbers (@N) after
+ * converting its bare-CR line ends.
+ */
+#ifndef VGPA_H
+#define VGPA_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGPA_ABI_VERSION 1
+
+/* error codes */
+#define VGPA_OK            0
+#define VGPA_EINVAL      (-1)   /* bad argument (null pointer, size, enum)        */
+#define VGPA_EUNSUPPORTED (-2)  /* D or N outside what the kernels are built for  */
+#define VGPA_ELAUNCH     (-3)   /* HIP reported a launch error                    */
+
+/* ODE integration method: core/fwd_ode.py:57-82, core/bwd_ode.py:58-83 */
+#define VGPA_EULER 0
+#define VGPA_HEUN  1
+#define VGPA_RK2   2
+#define VGPA_RK4   3
+
+/* dynamical system of an energy kernel */
+#define VGPA_SYS_OU      0   /* dynamics/sys_ornstein_uhlenbeck.py:83 */
+#define VGPA_SYS_DW      1   /* dynamics/sys_double_well.py:91        */
+#define VGPA_SYS_L63     2   /* dynamics/sys_lorenz_63.py:125         */
+#define VGPA_SYS_L63_UT  3   /* dynamics/sys_lorenz_63_ut.py:132      */
+#define VGPA_SYS_L96_UT  4   /* dynamics/sys_lorenz_96_ut.py:131      */
+
+/* per-step status bits written by the unscented kernels */
+#define VGPA_ST_CHOL_FALLBACK 1  /* chol((D+k)S) failed; diagonal fallback of
+                                    auxiliary/numerical.py:201-202 was used     */
+#define VGPA_ST_CHOL_FAILED   2  /* the fallback failed too (LinAlgError case)  */
+#define VGPA_ST_UNSUPPORTED   4  /* fallback needed but not available on device
+                                    for this D: outputs of this step are NaN    */
+
+/* gradient-assembly flags */
+#define VGPA_GRAD_OUTER 1        /* use outer products lam m', dEsde_db m' instead
+                                    of the reference's scalar inner products
+                                    (core/gradL_Ab.py:167,170).  Off by default. */
+#define VGPA_GRAD_SIGINV_DIAG 2  /* SigInv is diagonal: only its diagonal is read */
+
+/* largest state dimension the n-D kernels accept */
+#define VGPA_MAX_D 60
+
+int vgpa_version(void);
+const char* vgpa_last_error_string(void);
+
+/*
+ * Forward moment scan: replaces core/fwd_ode.py:48 `solver(A, b, m0, S0, Sigma,
+ * dt, method)` and its eight integrators (euler_nD :87, euler_1D :135, heun_nD
+ * :181, heun_1D :247, rk2_nD :311, rk2_1D :367, rk4_nD :426, rk4_1D :493).
+ *   A (P,N,D,D)  b (P,N,D)  m0 (P,D)  S0 (P,D,D)  Sigma (D,D) [sigma_stride]
+ *   -> m_out (P,N,D), S_out (P,N,D,D);  row 0 holds (m0, S0).
+ */
+int vgpa_fwd_scan(int method, int P, int N, int D,
+                  const double* A, const double* b,
+                  const double* m0, const double* S0,
+                  const double* Sigma, int sigma_stride, double dt,
+                  double* m_out, double* S_out, void* stream);
+
+/*
+ * Backward Lagrange-multiplier scan: replaces core/bwd_ode.py:50 `solver(A,
+ * dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, dt, method)` (euler_nD :86, euler_1D
+ * :132, heun :177/:241, rk2 :305/:367, rk4 :427/:497).
+ *   dEobs_dm (P,N,D) dense.  The covariance jumps are either dense
+ *   `dEobs_dS` (P,N,D,D), or -- when dEobs_dS is NULL -- `jumpS` (D,D)
+ *   [jumpS_stride] added at every row t with obs_flag[t] != 0 (obs_flag is (N)
+ *   int32, shared by all problems).  Both NULL means no covariance jumps.
+ *   -> lam_out (P,N,D), Psi_out (P,N,D,D); row N-1 is zero.
+ */
+int vgpa_bwd_scan(int method, int P, int N, int D,
+                  const double* A, const double* dEsde_dm, const double* dEsde_dS,
+                  const double* dEobs_dm, const double* dEobs_dS,
+                  const int* obs_flag, const double* jumpS, int jumpS_stride,
+                  double dt, double* lam_out, double* Psi_out, void* stream);
+
+/*
+ * Per-time-step expected SDE energy and its gradients: replaces the loop body of
+ * `energy_mode(A, b, m, S, sDyn)` -- dynamics/sys_ornstein_uhlenbeck.py:133-156,
+ * dynamics/sys_double_well.py:139-184, dynamics/sys_lorenz_63.py:202-233 (with
+ * Energy_dm_dS :247 and Efg_drift_theta :491), dynamics/sys_lorenz_63_ut.py:218-255,
+ * dynamics/sys_lorenz_96_ut.py:217-247 -- including the unscented transform
+ * (auxiliary/numerical.py:153-228) and core/gradEsde_mS.py:8-68 in closed form.
+ * The time integrals (mytrapz) are done by vgpa_reduce_energy on the per-step
+ * outputs.
+ *   sig_inv_diag (D) [sig_stride]  : diagonal of inv(Sigma)  (1-D: 1/Sigma)
+ *   theta (n_theta) [theta_stride] : drift parameters (1 value; 3 for Lorenz-63)
+ *   -> Esde_t (P,N)    0.5 * <(f-g)' SigInv (f-g)> at each step
+ *      Ef (P,N,D), Edf (P,N,D,D) [may be NULL for D > 1], dEsde_dm (P,N,D),
+ *      dEsde_dS (P,N,D,D)
+ *      dth_t (P,N,D or n_theta) [NULL ok] integrand of dEsde/dtheta before the
+ *            diag(SigInv) scaling;  dSig_t (P,N,D) [NULL ok] integrand of
+ *            dEsde/dSigma (the per-component <(f-g)^2>); unused for D == 1
+ *      status (P,N) int32 [NULL ok] VGPA_ST_* bits (unscented systems only)
+ */
+int vgpa_esde(int system, int P, int N, int D,
+              const double* A, const double* b, const double* m, const double* S,
+              const double* sig_inv_diag, int sig_stride,
+              const double* theta, int theta_stride,
+              double* Esde_t, double* Ef, double* Edf,
+              double* dEsde_dm, double* dEsde_dS,
+              double* dth_t, double* dSig_t, int* status, void* stream);
+
+/* Same as vgpa_esde with the system fixed (one symbol per kernel family). */
+#define VGPA_DECL_ESDE(name)                                                      \
+    int name(int P, int N, int D, const double* A, const double* b,               \
+             const double* m, const double* S, const double* sig_inv_diag,        \
+             int sig_stride, const double* theta, int theta_stride,               \
+             double* Esde_t, double* Ef, double* Edf, double* dEsde_dm,           \
+             double* dEsde_dS, double* dth_t, double* dSig_t, int* status,        \
+             void* stream)
+VGPA_DECL_ESDE(vgpa_esde_ou);
+VGPA_DECL_ESDE(vgpa_esde_dw);
+VGPA_DECL_ESDE(vgpa_esde_l63);
+VGPA_DECL_ESDE(vgpa_esde_l63_ut);
+VGPA_DECL_ESDE(vgpa_esde_l96_ut);
+
+/*
+ * Weighted time reduction out[p,c] = scale * sum_t w[t] * x[p,t,c]: with the
+ * weights of the segmented trapezoid rule this replaces `mytrapz(fxt, dt, idx)`,
+ * auxiliary/numerical.py:231-284 (w has zeros from the last observation on).
+ * Time-window shards pass their slice of w, so partial sums add exactly.
+ *   x (P,N,C)  w (N)  -> out (P,C).  Deterministic summation order.
+ */
+int vgpa_reduce_energy(int P, int N, int C, const double* x, const double* w,
+                       double scale, double* out, void* stream);
+
+/*
+ * Observation energy and jump terms: replaces core/likelihood.py@13 `gauss(m, S,
+ * sde_struct)` (gauss_1D @52, gauss_nD @108).
+ *   obs_idx (M) int32 time indices; obsY (M,d) [obsY_stride]; H (D,d);
+ *   Ri (d,d) and Qi (d,d) as returned by chol_inv(R) (auxiliary/numerical.py:10-48);
+ *   logconst = M * (d*log(2 pi) + log det R).  For D == 1: H, Ri are single
+ *   values, Qi is unused.
+ *   -> Eobs (P); dEobs_dm (P,N,D) (zeroed, then rows obs_idx filled);
+ *      jumpS (D,D) = 0.5 H' Ri H (the value of dEobs_dS at every observed row).
+ */
+int vgpa_obs_terms(int P, int N, int D, int M, int d,
+                   const double* m, const double* S,
+                   const int* obs_idx, const double* obsY, int obsY_stride,
+                   const double* H, const double* Ri, const double* Qi,
+                   double logconst,
+                   double* Eobs, double* dEobs_dm, double* jumpS, void* stream);
+
+/*
+ * Initial-state KL energy: replaces core/kl0.py:9 `gauss(m0, S0, lam, Psi,
+ * sde_struct)` (energy only; gauss_1D :49, gauss_nD :72).  `m0_is_row` selects
+ * the outer-product form the reference produces for a (1,D) mean; 0 gives the
+ * scalar |z0|^2 broadcast it produces for a (D,) mean (core/kl0.py:88-90).
+ *   m0 (P,D) S0 (P,D,D) mu0 (D) [mu0_stride] tau0 (D,D) [tau0_stride] -> KL0 (P)
+ */
+int vgpa_kl0(int P, int D, const double* m0, const double* S0,
+             const double* mu0, int mu0_stride, const double* tau0, int tau0_stride,
+             int m0_is_row, double* KL0, void* stream);
+
+/*
+ * Gradient of the Lagrangian w.r.t. A(t), b(t): replaces core/gradL_Ab.py:50
+ * `gradL_Ab_1D` and :112 `gradL_Ab_nD` (the loop :156-173 and the dt scaling
+ * :176-177).  SigInv (D,D) [sig_stride] is inv(Sigma) (1-D: 1/Sigma).
+ *   -> gLA (P,N,D,D), gLb (P,N,D), already multiplied by dt.
+ */
+int vgpa_grad_assemble(int P, int N, int D,
+                       const double* A, const double* b, const double* m, const double* S,
+                       const double* lam, const double* Psi,
+                       const double* Ef, const double* Edf,
+                       const double* SigInv, int sig_stride, double dt, int flags,
+                       double* gLA, double* gLb, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGPA_H */

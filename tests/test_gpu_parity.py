@@ -1,0 +1,270 @@
+"""Parity of the HIP path (through the C ABI and the reference-signature entry
+points) against the golden vectors recorded from the reference and against the
+CPU oracle.  Tolerance: 1e-9 max-norm relative, the bar the free energy and the
+gradients are held to."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr, sde_from_golden, initial_moments
+from oracle import vgpa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+METHODS = ("EULER", "HEUN", "RK2", "RK4")
+SYSTEMS = [("ou", "sys_ou.npz"), ("dw", "sys_dw.npz"), ("l63", "sys_l63.npz"),
+           ("l63_ut", "sys_l63_ut.npz"), ("l96_ut", "sys_l96_ut_d6.npz"),
+           ("l96_ut", "sys_l96_ut_d40.npz")]
+
+
+def _dyn(system):
+    from vgpa_amd.dynamics import (sys_ornstein_uhlenbeck, sys_double_well, sys_lorenz_63,
+                                   sys_lorenz_63_ut, sys_lorenz_96_ut)
+    return dict(ou=sys_ornstein_uhlenbeck, dw=sys_double_well, l63=sys_lorenz_63,
+                l63_ut=sys_lorenz_63_ut, l96_ut=sys_lorenz_96_ut)[system]
+
+
+@pytest.mark.parametrize("system,fname", SYSTEMS)
+@pytest.mark.parametrize("method", METHODS)
+def test_free_energy_and_gradient_vs_golden(system, fname, method):
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core.gradL_Ab import gradL_Ab
+    g = load_golden(fname)
+    sde = sde_from_golden(g, method)
+    m0, S0 = initial_moments(g)
+    mParam = dict(m0=m0, S0=S0, fun=_dyn(system).energy_mode, sde_struct=sde)
+    F = varFreeEnergy(g["Ab"], mParam)
+    assert isinstance(F, float)
+    Fref = float(g[f"{method}.F"])
+    assert abs(F - Fref) <= TOL * abs(Fref)
+    grad = gradL_Ab(g["Ab"], mParam)
+    assert grad.shape == g[f"{method}.grad"].shape
+    assert relerr(grad, g[f"{method}.grad"]) <= TOL
+    # evalF=True recomputes on a private copy and must give the same column
+    keep = {k: np.array(v, copy=True) for k, v in mParam.items() if isinstance(v, np.ndarray)}
+    grad2 = gradL_Ab(g["Ab"], mParam, True)
+    assert relerr(grad2, g[f"{method}.grad"]) <= TOL
+    for k, v in keep.items():
+        assert np.array_equal(mParam[k], v)
+    # side effects with the reference's shapes
+    for key, gk in (("mt", "m"), ("St", "S"), ("lamt", "lam"), ("Psit", "Psi"), ("Efx", "Ef"), ("Edf", "Edf")):
+        name = f"{method}.{gk}"
+        if name in g:
+            assert mParam[key].shape == g[name].shape, key
+            assert relerr(mParam[key], g[name]) <= TOL, key
+
+
+@pytest.mark.parametrize("system,fname", SYSTEMS)
+def test_energy_mode_vs_golden(system, fname):
+    g = load_golden(fname)
+    sde = sde_from_golden(g, "EULER")
+    N, D = sde["N"], sde["D"]
+    A, b = orc.unpack_Ab(g["Ab"], N, D)
+    out = _dyn(system).energy_mode(A, b, g["EULER.m"], g["EULER.S"], sde)
+    assert len(out) == 7
+    names = ["Esde", "Ef", "Edf", "dEsde_dm", "dEsde_dS", "dEsde_dth", "dEsde_dSig"]
+    for n, v in zip(names, out):
+        gk = f"EULER.{n}"
+        if gk in g:
+            assert relerr(v, g[gk]) <= TOL, n
+            assert np.asarray(v).shape == np.asarray(g[gk]).shape, n
+
+
+@pytest.mark.parametrize("D", [1, 3, 6, 40])
+@pytest.mark.parametrize("method", METHODS)
+def test_scans_vs_oracle_random_inputs(D, method):
+    """fwd_ode.solver / bwd_ode.solver on inputs with no special structure
+    (non-symmetric S0, Sigma, dEsde_dS, dense jumps)."""
+    from vgpa_amd.core import fwd_ode, bwd_ode
+    rng = np.random.default_rng(100 + D)
+    N, dt = (23 if D > 1 else 57), 0.01
+    if D == 1:
+        A = 2.0 + 0.5 * rng.standard_normal((N, 1))
+        b = rng.standard_normal((N, 1))
+        m0, S0, Sig = np.array([0.3]), 0.25, 0.8
+        gm, gS = rng.standard_normal((N, 1)), rng.standard_normal((N, 1))
+        jm, jS = rng.standard_normal((N, 1)), rng.standard_normal((N, 1))
+    else:
+        A = 4.0 * np.eye(D)[None] + 0.5 * rng.standard_normal((N, D, D))
+        b = rng.standard_normal((N, D))
+        m0 = rng.standard_normal(D)
+        S0 = 0.25 * np.eye(D) + 0.05 * rng.standard_normal((D, D))
+        Sig = 2.0 * np.eye(D) + 0.1 * rng.standard_normal((D, D))
+        gm, gS = rng.standard_normal((N, D)), rng.standard_normal((N, D, D))
+        jm, jS = rng.standard_normal((N, D)), rng.standard_normal((N, D, D))
+    m, S = fwd_ode.solver(A, b, m0, S0, Sig, dt, method)
+    mr, Sr = orc.fwd_scan(A, b, m0, S0, Sig, dt, method)
+    assert m.shape == mr.shape and S.shape == Sr.shape
+    assert relerr(m, mr) <= TOL and relerr(S, Sr) <= TOL
+    lam, Psi = bwd_ode.solver(A, gm, gS, jm, jS, dt, method.lower())
+    lr, Pr = orc.bwd_scan(A, gm, gS, jm, jS, dt, method)
+    assert lam.shape == lr.shape and Psi.shape == Pr.shape
+    assert relerr(lam, lr) <= TOL and relerr(Psi, Pr) <= TOL
+
+
+def test_unknown_method_raises_like_the_reference():
+    from vgpa_amd.core import fwd_ode, bwd_ode
+    A, b = np.ones((5, 1)), np.ones((5, 1))
+    with pytest.raises(ValueError, match="Unknown method of integration"):
+        fwd_ode.solver(A, b, np.array([0.0]), 0.25, 1.0, 0.01, "midpoint")
+    with pytest.raises(ValueError, match="Unknown method of integration"):
+        bwd_ode.solver(A, b, b, b, b, 0.01, "midpoint")
+
+
+@pytest.mark.parametrize("fname", ["sys_ou.npz", "sys_l63_ut.npz", "sys_l96_ut_d40.npz"])
+def test_likelihood_and_kl0_vs_golden(fname):
+    from vgpa_amd.core import likelihood, kl0
+    g = load_golden(fname)
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    Eobs, dm, dS, dR = likelihood.gauss(g["EULER.m"], g["EULER.S"], sde)
+    assert relerr(Eobs, g["EULER.Eobs"]) <= TOL
+    assert relerr(dm, g["EULER.dEobs_dm"]) <= TOL
+    ref = orc.likelihood_gauss(g["EULER.m"], g["EULER.S"], sde)
+    assert dS.shape == ref[2].shape and relerr(dS, ref[2]) <= TOL
+    K, dKm, dKS = kl0.gauss(m0, S0, g["EULER.lam"], g["EULER.Psi"], sde)
+    assert relerr(K, g["EULER.KL0"]) <= TOL
+    assert np.shape(K) == np.shape(g["EULER.KL0"])
+
+
+def test_kl0_depends_on_the_shape_of_m0():
+    from vgpa_amd.core import kl0
+    g = load_golden("units.npz")
+    sde = dict(D=5, px0=dict(mu0=g["kl0.mu0"], tau0=g["kl0.tau0"]))
+    lam, Psi = np.zeros((2, 5)), np.zeros((2, 5, 5))
+    vec = kl0.gauss(g["kl0.m0"], g["kl0.S0"], lam, Psi, sde)[0]
+    row = kl0.gauss(g["kl0.m0"][None, :], g["kl0.S0"], lam, Psi, sde)[0]
+    assert relerr(vec, g["kl0.vec"]) <= TOL
+    assert relerr(row, g["kl0.row"]) <= TOL
+    sde1 = dict(D=1, px0=dict(mu0=0.3, tau0=0.5))
+    one = kl0.gauss(np.array([0.45]), 0.25, np.zeros((2, 1)), np.zeros((2, 1)), sde1)[0]
+    assert relerr(one, g["kl0.1d"]) <= TOL
+
+
+def test_lorenz63_unscented_cholesky_fallback_vs_golden():
+    from vgpa_amd.dynamics import sys_lorenz_63_ut
+    g = load_golden("l63_ut_nonpd.npz")
+    sde = sde_from_golden(g)
+    A, b = orc.unpack_Ab(g["Ab"], sde["N"], sde["D"])
+    out = sys_lorenz_63_ut.energy_mode(A, b, g["m"], g["S"], sde)
+    names = ["Esde", "Ef", "Edf", "dEsde_dm", "dEsde_dS", "dEsde_dth", "dEsde_dSig"]
+    for n, v in zip(names, out):
+        assert relerr(v, g[n]) <= TOL, n
+
+
+def test_lorenz96_non_positive_definite_covariance_is_reported():
+    from vgpa_amd.dynamics import sys_lorenz_96_ut
+    g = load_golden("units.npz")
+    St, mt, At, bt = (g[f"ut.l96_npd.{k}"] for k in ("St", "mt", "At", "bt"))
+    D = mt.size
+    sde = dict(N=1, D=D, dt=0.01, Sig=np.eye(D), theta=8.0, obsX=np.array([0]))
+    with pytest.raises(np.linalg.LinAlgError):
+        sys_lorenz_96_ut.energy_mode(At[None], bt[None], mt[None], St[None], sde)
+
+
+@pytest.mark.parametrize("tag,system", [("l63", "l63_ut"), ("l96", "l96_ut")])
+def test_unscented_single_step_vs_golden(tag, system):
+    """The closed-form sigma-point reduction of the kernels against the
+    per-sigma-point vectors ut_approx / gradEsde_mS produced in the reference."""
+    g = load_golden("units.npz")
+    St, mt, At, bt = (g[f"ut.{tag}.{k}"] for k in ("St", "mt", "At", "bt"))
+    dSigI, theta = g[f"ut.{tag}.dSigI"], g[f"ut.{tag}.theta"]
+    D = mt.size
+    sde = dict(N=1, D=D, dt=0.01, Sig=np.diag(1.0 / dSigI), theta=(theta if D == 3 else float(theta)),
+               obsX=np.array([0]))
+    out = _dyn(system).energy_mode(At[None], bt[None], mt[None], St[None], sde)
+    Ef, dEdm, dEdS = out[1], out[3], out[4]
+    mbar, dmS = g[f"ut.{tag}.mbar"].ravel(), g[f"ut.{tag}.dmS"].ravel()
+    Esde_t = 0.5 * dSigI.dot(mbar)
+    dm_ref = dmS[:D] - Esde_t * np.linalg.solve(St, mt)
+    dS_ref = 0.5 * (dmS[D:].reshape(D, D) - Esde_t * np.linalg.inv(St))
+    assert relerr(dEdm[0], dm_ref) <= TOL
+    assert relerr(dEdS[0], dS_ref) <= TOL
+
+
+def test_batched_grid_matches_per_problem_oracle():
+    """Several Lorenz-63 problems with different drift parameters in one launch."""
+    import torch
+    from vgpa_amd import engine, _lib
+    g = load_golden("sys_l63_ut.npz")
+    sde = sde_from_golden(g, "RK2")
+    m0, S0 = initial_moments(g)
+    N, D = sde["N"], sde["D"]
+    rng = np.random.default_rng(5)
+    P = 5
+    thetas = np.array(sde["theta"])[None, :] * (1.0 + 0.1 * rng.standard_normal((P, 3)))
+    A0, b0 = orc.unpack_Ab(g["Ab"], N, D)
+    A = A0[None] + 0.05 * rng.standard_normal((P, N, D, D))
+    b = b0[None] + 0.05 * rng.standard_normal((P, N, D))
+    for system, sid in (("l63_ut", _lib.SYS_L63_UT), ("l63", _lib.SYS_L63)):
+        prob = engine.make_problem(sid, sde, m0, S0, P=P, theta=thetas)
+        Ad, bd = engine.to_dev(A), engine.to_dev(b)
+        st = engine.free_energy(prob, Ad, bd, want_hyper=True)
+        gLA, gLb = engine.gradient(prob, Ad, bd, st)
+        for p in range(P):
+            sp = dict(sde, theta=thetas[p])
+            Ab = np.concatenate((A[p].ravel(), b[p].ravel()))
+            ref = orc.evaluate(system, Ab, m0, S0, sp)
+            assert abs(st.F[p].item() - ref["F"]) <= TOL * abs(ref["F"])
+            got = np.concatenate((gLA[p].reshape(-1).cpu().numpy(), gLb[p].reshape(-1).cpu().numpy()))
+            assert relerr(got, ref["grad"]) <= TOL
+            assert relerr(st.dth[p].cpu().numpy(), ref["dEsde_dth"]) <= TOL
+            assert relerr(st.dSig[p].cpu().numpy(), ref["dEsde_dSig"]) <= TOL
+
+
+def test_outer_product_variant_is_opt_in():
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core.gradL_Ab import gradL_Ab
+    g = load_golden("sys_l96_ut_d6.npz")
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    mParam = dict(m0=m0, S0=S0, fun=_dyn("l96_ut").energy_mode, sde_struct=sde)
+    varFreeEnergy(g["Ab"], mParam)
+    got = gradL_Ab(g["Ab"], mParam, outer=True)
+    ref = orc.evaluate("l96_ut", g["Ab"], m0, S0, sde, outer=True)["grad"]
+    assert relerr(got, ref) <= TOL
+    assert relerr(got, g["EULER.grad"]) > 1e-3
+
+
+def test_full_size_lorenz96_sampled_against_oracle():
+    """Headline size (D=40, N=2002): the oracle re-evaluates the per-step energy
+    kernel on a sample of time steps of the device trajectory, and the weighted time
+    sum; determinism is checked by running twice."""
+    import torch
+    from vgpa_amd import engine, _lib
+    rng = np.random.default_rng(20240)
+    D, N, dt, P = 40, 2002, 0.005, 2
+    A = 8.0 * np.eye(D)[None, None] + 0.1 * rng.standard_normal((P, N, D, D))
+    b = 5.0 * rng.standard_normal((P, N, D))
+    obsX = np.arange(25, N, 25)
+    mu0 = rng.standard_normal(D)
+    sde = dict(Sig=4.0 * np.eye(D), theta=8.0, Rig=np.eye(D), D=D, N=N, H=np.eye(D), obsX=obsX,
+               obsY=3.0 * rng.standard_normal((obsX.size, D)), px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)),
+               dt=dt, ode_method="EULER")
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, mu0 + 0.1, 0.25 * np.eye(D), P=P)
+    Ad, bd = engine.to_dev(A), engine.to_dev(b)
+    st = engine.free_energy(prob, Ad, bd, want_hyper=True)
+    gLA, gLb = engine.gradient(prob, Ad, bd, st)
+    assert int(st.status.max().item()) == 0
+    st2 = engine.free_energy(prob, Ad, bd, want_hyper=True)
+    assert torch.equal(st.F, st2.F) and torch.equal(st.Psi, st2.Psi)
+    # sampled steps through the oracle's literal per-sigma-point formulas
+    ts = np.sort(rng.choice(N, size=24, replace=False))
+    p = 1
+    m, S = st.m[p].cpu().numpy(), st.S[p].cpu().numpy()
+    assert relerr(S, np.swapaxes(S, 1, 2)) <= 1e-12
+    sI = np.full(D, 0.25)
+    Et, mbar, dEdm, dEdS, flag = orc._ut_energy(lambda x: orc.lorenz96(x, 8.0), A[p, ts], b[p, ts], m[ts], S[ts], sI)
+    assert relerr(st.dEdm[p].cpu().numpy()[ts], dEdm) <= TOL
+    assert relerr(st.dEdS[p].cpu().numpy()[ts], dEdS) <= TOL
+    # full scans, observation terms, KL0 and gradient assembly through the oracle
+    # (cheap on the CPU: no per-step factorisations)
+    mr, Sr = orc.fwd_scan(A[p], b[p], mu0 + 0.1, 0.25 * np.eye(D), sde["Sig"], dt)
+    assert relerr(m, mr) <= TOL and relerr(S, Sr) <= TOL
+    Eobs, jm, jS = orc.likelihood_gauss(m, S, sde)
+    assert abs(st.Eobs[p].item() - Eobs) <= TOL * abs(Eobs)
+    lam, Psi = orc.bwd_scan(A[p], st.dEdm[p].cpu().numpy(), st.dEdS[p].cpu().numpy(), jm, jS, dt)
+    assert relerr(st.lam[p].cpu().numpy(), lam) <= TOL and relerr(st.Psi[p].cpu().numpy(), Psi) <= TOL
+    gr = orc.grad_L_Ab(A[p], b[p], m, S, lam, Psi, st.Ef[p].cpu().numpy(), st.Edf[p].cpu().numpy(), sde["Sig"], dt)
+    got = np.concatenate((gLA[p].reshape(-1).cpu().numpy(), gLb[p].reshape(-1).cpu().numpy()))
+    assert relerr(got, gr) <= TOL

@@ -1,0 +1,88 @@
+"""ctypes binding of ``libvgpa_hip.so`` (declared in ``include/vgpa.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or
+``python -m vgpa_amd.build``).  There is no CPU implementation behind these
+entry points: if the shared object is missing the import fails, and if no HIP
+device is present every compute call raises.
+"""
+import ctypes
+import os
+
+# PyTorch ships its own HIP runtime (libamdhip64.so.7).  It has to be in the process
+# before libvgpa_hip.so is loaded so that the dynamic loader binds the kernels to that
+# same runtime instance: device pointers and streams are only meaningful within one.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvgpa_hip.so")
+
+ABI_VERSION = 1
+
+# enums of include/vgpa.h
+EULER, HEUN, RK2, RK4 = 0, 1, 2, 3
+METHODS = {"EULER": EULER, "HEUN": HEUN, "RK2": RK2, "RK4": RK4}
+SYS_OU, SYS_DW, SYS_L63, SYS_L63_UT, SYS_L96_UT = 0, 1, 2, 3, 4
+SYSTEMS = {"ou": SYS_OU, "dw": SYS_DW, "l63": SYS_L63, "l63_ut": SYS_L63_UT, "l96_ut": SYS_L96_UT}
+ST_CHOL_FALLBACK, ST_CHOL_FAILED, ST_UNSUPPORTED = 1, 2, 4
+GRAD_OUTER, GRAD_SIGINV_DIAG = 1, 2
+MAX_D = 60
+
+_c_int, _c_dbl, _ptr = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+_ESDE_ARGS = [_c_int, _c_int, _c_int] + [_ptr] * 4 + [_ptr, _c_int, _ptr, _c_int] + [_ptr] * 8 + [_ptr]
+
+# name -> argtypes; every function returns int except the two noted below
+SIGNATURES = {
+    "vgpa_fwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl, _ptr, _ptr, _ptr],
+    "vgpa_bwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl,
+                      _ptr, _ptr, _ptr],
+    "vgpa_esde": [_c_int] + _ESDE_ARGS,
+    "vgpa_esde_ou": _ESDE_ARGS,
+    "vgpa_esde_dw": _ESDE_ARGS,
+    "vgpa_esde_l63": _ESDE_ARGS,
+    "vgpa_esde_l63_ut": _ESDE_ARGS,
+    "vgpa_esde_l96_ut": _ESDE_ARGS,
+    "vgpa_reduce_energy": [_c_int, _c_int, _c_int, _ptr, _ptr, _c_dbl, _ptr, _ptr],
+    "vgpa_obs_terms": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
+                       _c_dbl, _ptr, _ptr, _ptr, _ptr],
+    "vgpa_kl0": [_c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _ptr],
+    "vgpa_grad_assemble": [_c_int, _c_int, _c_int] + [_ptr] * 9 + [_c_int, _c_dbl, _c_int, _ptr, _ptr, _ptr],
+}
+EXPORTS = ["vgpa_version", "vgpa_last_error_string"] + list(SIGNATURES)
+
+
+class VgpaError(RuntimeError):
+    """A libvgpa_hip.so entry point returned a negative status."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vgpa_version.restype = _c_int
+    lib.vgpa_version.argtypes = []
+    lib.vgpa_last_error_string.restype = ctypes.c_char_p
+    lib.vgpa_last_error_string.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _c_int
+        fn.argtypes = args
+    if lib.vgpa_version() != ABI_VERSION:
+        raise ImportError(f"libvgpa_hip.so ABI {lib.vgpa_version()} != expected {ABI_VERSION}: rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def call(name, *args):
+    """Call an entry point and raise VgpaError (ValueError for a bad integration
+    method, as the reference does) on a negative return code."""
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.vgpa_last_error_string().decode("utf-8", "replace")
+        if "Unknown method of integration" in msg:
+            raise ValueError("Unknown method of integration")
+        raise VgpaError(f"{name} failed ({rc}): {msg}")

@@ -1,0 +1,476 @@
+// Time reductions, observation terms, initial-state KL energy and the assembly of
+// dL/dA, dL/db, gfx950.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// out[p,c] = scale * sum_t w[t] x[p,t,c]     (auxiliary/numerical.py:231-284 as a
+// weighted sum).  One workgroup per problem; lanes run over the contiguous (t,c)
+// plane, partial sums are combined in a fixed order.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+reduce_energy_kernel(int N, int C, const double* __restrict__ x, const double* __restrict__ w,
+                     double scale, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int p = blockIdx.x;
+    const int T = 256 / C;            // time lanes per column (C <= 256)
+    const int tid = threadIdx.x;
+    const int c = tid % C, t0 = tid / C;
+    double acc = 0.0;
+    if (tid < T * C) {
+        const double* xp = x + (size_t)p * N * C;
+        for (int t = t0; t < N; t += T) acc = fma(w[t], xp[(size_t)t * C + c], acc);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < C) {
+        double s = 0.0;
+        for (int k = 0; k < T; ++k) s += red[k * C + tid];
+        out[(size_t)p * C + tid] = scale * s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Observation terms, D > 1: one wavefront per problem, observations in sequence.
+// core/likelihood.py@108-179.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+obs_terms_nd_kernel(int N, int D, int M, const double* __restrict__ m, const double* __restrict__ S,
+                    const int* __restrict__ obs_idx, const double* __restrict__ obsY, int obsY_stride,
+                    const double* __restrict__ H, const double* __restrict__ Ri, const double* __restrict__ Qi,
+                    double logconst, double* __restrict__ Eobs, double* __restrict__ dEobs_dm,
+                    double* __restrict__ jumpS) {
+    extern __shared__ double lds[];
+    double* Wv = lds;          // W_n = y_n - m(t_n) H
+    double* Tv = lds + D;      // Ri W_n
+    const int p = blockIdx.x, l = threadIdx.x;
+    const size_t DD = (size_t)D * D;
+    const double* Y = obsY + (size_t)p * obsY_stride;
+    double e_acc = 0.0;        // per-lane share of sum_n (Z_n.Z_n + diag(Ri).diag(S_n))
+    for (int n = 0; n < M; ++n) {
+        const int tn = obs_idx[n];
+        const double* mt = m + ((size_t)p * N + tn) * D;
+        __syncthreads();
+        if (l < D) {
+            double hm = 0.0;
+            for (int i = 0; i < D; ++i) hm = fma(mt[i], H[i * D + l], hm);       // (m H)[l]
+            Wv[l] = Y[(size_t)n * D + l] - hm;
+        }
+        __syncthreads();
+        if (l < D) {
+            double z = 0.0, t = 0.0;
+            for (int j = 0; j < D; ++j) {
+                z = fma(Wv[j], Qi[l * D + j], z);                                 // (W Qi')[l]
+                t = fma(Ri[l * D + j], Wv[j], t);                                 // (Ri W)[l]
+            }
+            Tv[l] = t;
+            e_acc += z * z + Ri[l * D + l] * S[((size_t)p * N + tn) * DD + (size_t)l * D + l];
+        }
+        __syncthreads();
+        if (l < D) {
+            double gsum = 0.0;
+            for (int k = 0; k < D; ++k) gsum = fma(H[k * D + l], Tv[k], gsum);   // (H' Ri W)[l]
+            dEobs_dm[((size_t)p * N + tn) * D + l] = -gsum;
+        }
+    }
+    double tot = e_acc;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    if (l == 0) Eobs[p] = 0.5 * (tot + logconst);
+    if (p == 0 && jumpS) {
+        // 0.5 H' Ri H
+        for (int q = l; q < (int)DD; q += 64) {
+            const int i = q / D, j = q % D;
+            double s = 0.0;
+            for (int a = 0; a < D; ++a) {
+                double rh = 0.0;
+                for (int c = 0; c < D; ++c) rh = fma(Ri[a * D + c], H[c * D + j], rh);
+                s = fma(H[a * D + i], rh, s);
+            }
+            jumpS[q] = 0.5 * s;
+        }
+    }
+}
+
+// D == 1: one lane per problem.  core/likelihood.py@52-105 (the energy uses
+// Y^2 - 2 Y m + <x^2> without H, the jump uses W = Y - H m; both as written).
+__global__ void obs_terms_1d_kernel(int P, int N, int M, const double* __restrict__ m, const double* __restrict__ S,
+                                    const int* __restrict__ obs_idx, const double* __restrict__ obsY, int obsY_stride,
+                                    const double* __restrict__ Hp, const double* __restrict__ Rip, double logconst,
+                                    double* __restrict__ Eobs, double* __restrict__ dEobs_dm,
+                                    double* __restrict__ jumpS) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double H = Hp[0], Ri = Rip[0];
+    const double* Y = obsY + (size_t)p * obsY_stride;
+    double s = 0.0;
+    for (int n = 0; n < M; ++n) {
+        const int tn = obs_idx[n];
+        const double mt = m[(size_t)p * N + tn], St = S[(size_t)p * N + tn], y = Y[n];
+        s += y * y - 2 * y * mt + (mt * mt + St);
+        dEobs_dm[(size_t)p * N + tn] = -Ri * (y - H * mt);
+    }
+    Eobs[p] = 0.5 * Ri * s + 0.5 * logconst;
+    if (p == 0 && jumpS) jumpS[0] = 0.5 * Ri;
+}
+
+// ---------------------------------------------------------------------------
+// KL0, D > 1: one wavefront per problem, matrices in LDS.  core/kl0.py:72-99.
+// ---------------------------------------------------------------------------
+// In-place Gauss-Jordan inverse with partial pivoting of the D x D matrix M
+// (row stride LD) using the D x D scratch I (same stride); result in I.
+__device__ void gj_inverse(double* M, double* I, int D, int LD, int l) {
+    for (int q = l; q < D * D; q += 64) I[(q / D) * LD + (q % D)] = (q / D == q % D) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int k = 0; k < D; ++k) {
+        // pivot search over rows k..D-1 of column k
+        double best = -1.0;
+        int brow = k;
+        for (int r = k + l; r < D; r += 64) {
+            const double v = fabs(M[r * LD + k]);
+            if (v > best) { best = v; brow = r; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int orow = __shfl_xor(brow, off, 64);
+            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+        }
+        if (brow != k) {
+            for (int j = l; j < D; j += 64) {
+                double t = M[k * LD + j]; M[k * LD + j] = M[brow * LD + j]; M[brow * LD + j] = t;
+                t = I[k * LD + j]; I[k * LD + j] = I[brow * LD + j]; I[brow * LD + j] = t;
+            }
+        }
+        __syncthreads();
+        const double rp = 1.0 / M[k * LD + k];
+        __syncthreads();
+        for (int j = l; j < D; j += 64) { M[k * LD + j] *= rp; I[k * LD + j] *= rp; }
+        __syncthreads();
+        for (int r = 0; r < D; ++r) {
+            if (r == k) continue;
+            const double f = M[r * LD + k];
+            __syncthreads();
+            for (int j = l; j < D; j += 64) {
+                M[r * LD + j] = fma(-f, M[k * LD + j], M[r * LD + j]);
+                I[r * LD + j] = fma(-f, I[k * LD + j], I[r * LD + j]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64)
+kl0_nd_kernel(int D, const double* __restrict__ m0, const double* __restrict__ S0,
+              const double* __restrict__ mu0, int mu0_stride, const double* __restrict__ tau0, int tau0_stride,
+              int m0_is_row, double* __restrict__ KL0) {
+    extern __shared__ double lds[];
+    const int LD = D + 1, MS = D * LD;
+    double* Ma = lds;             // work copy
+    double* S0i = lds + MS;       // inv(S0)
+    double* T0i = lds + 2 * MS;   // inv(tau0)
+    double* Pm = lds + 3 * MS;    // tau0 * inv(S0), then its Cholesky factor
+    double* z = lds + 4 * MS;
+    const int p = blockIdx.x, l = threadIdx.x;
+    const size_t DD = (size_t)D * D;
+    const double* S0p = S0 + (size_t)p * DD;
+    const double* t0p = tau0 + (size_t)p * tau0_stride;
+    for (int q = l; q < (int)DD; q += 64) Ma[(q / D) * LD + (q % D)] = S0p[q];
+    if (l < D) z[l] = m0[(size_t)p * D + l] - mu0[(size_t)p * mu0_stride + l];
+    __syncthreads();
+    gj_inverse(Ma, S0i, D, LD, l);
+    for (int q = l; q < (int)DD; q += 64) Ma[(q / D) * LD + (q % D)] = t0p[q];
+    __syncthreads();
+    gj_inverse(Ma, T0i, D, LD, l);
+    // Pm = tau0 * S0i
+    for (int q = l; q < (int)DD; q += 64) {
+        const int i = q / D, j = q % D;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s = fma(t0p[i * D + k], S0i[k * LD + j], s);
+        Pm[i * LD + j] = s;
+    }
+    __syncthreads();
+    // log det via Cholesky of the lower triangle (auxiliary/numerical.py:86)
+    double logdet = 0.0;
+    bool ok = true;
+    for (int j = 0; j < D; ++j) {
+        const double djj = Pm[j * LD + j];
+        if (!(djj > 0.0)) { ok = false; break; }
+        const double d = sqrt(djj);
+        logdet += log(d);
+        double lij = 0.0;
+        if (l < D && l > j) { lij = Pm[l * LD + j] / d; }
+        __syncthreads();
+        if (l < D && l > j) Pm[l * LD + j] = lij;
+        __syncthreads();
+        for (int k = j + 1; k < D; ++k) {
+            const double lkj = Pm[k * LD + j];
+            if (l < D && l >= k) Pm[l * LD + k] = fma(-lij, lkj, Pm[l * LD + k]);
+        }
+        __syncthreads();
+    }
+    // trace(tau0i (Z + S0 - tau0)),  Z = z z' (row mean) or |z|^2 in every entry
+    double zz = 0.0;
+    for (int k = 0; k < D; ++k) zz = fma(z[k], z[k], zz);
+    double tr = 0.0;
+    for (int q = l; q < (int)DD; q += 64) {
+        const int i = q / D, j = q % D;
+        const double Z = m0_is_row ? z[j] * z[i] : zz;
+        tr = fma(T0i[i * LD + j], Z + S0p[j * D + i] - t0p[j * D + i], tr);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tr += __shfl_xor(tr, off, 64);
+    if (l == 0) KL0[p] = ok ? 0.5 * (2.0 * logdet + tr) : __builtin_nan("");
+}
+
+// core/kl0.py:49-69 (note -log(S0), not -0.5 log(S0)).
+__global__ void kl0_1d_kernel(int P, const double* __restrict__ m0, const double* __restrict__ S0,
+                              const double* __restrict__ mu0, int mu0_stride, const double* __restrict__ tau0,
+                              int tau0_stride, double* __restrict__ KL0) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double t0 = tau0[(size_t)p * tau0_stride];
+    const double z0 = m0[p] - mu0[(size_t)p * mu0_stride];
+    KL0[p] = -log(S0[p]) - 0.5 * (1.0 - log(t0)) + 0.5 / t0 * (z0 * z0 + S0[p]);
+}
+
+// ---------------------------------------------------------------------------
+// Gradient assembly, D > 1: one workgroup per (problem, step).
+// core/gradL_Ab.py:156-177.  gLA = dt ( [SigInv (Edf + A) - 2 Psi] S - s1 - s2 ).
+// ---------------------------------------------------------------------------
+constexpr int GI = 2, GJ = 4;
+
+__global__ void __launch_bounds__(512)
+grad_assemble_nd_kernel(int N, int D, const double* __restrict__ A, const double* __restrict__ b,
+                        const double* __restrict__ m, const double* __restrict__ S,
+                        const double* __restrict__ lam, const double* __restrict__ Psi,
+                        const double* __restrict__ Ef, const double* __restrict__ Edf,
+                        const double* __restrict__ SigInv, int sig_stride, int sig_diag, double dt, int flags,
+                        double* __restrict__ gLA, double* __restrict__ gLb) {
+    extern __shared__ double lds[];
+    const int LD = D + 1, MS = D * LD;
+    double* Xm = lds;             // A, then SigInv (Edf + A) - 2 Psi
+    double* Sm = lds + MS;        // S(t)
+    double* Ym = lds + 2 * MS;    // Edf + A (general SigInv only)
+    double* mv = lds + 3 * MS;
+    double* uv = mv + D;          // -Ef - A m + b
+    double* dbv = uv + D;
+    double* lv = dbv + D;
+    double* sc = lv + D;          // two scalars
+    const size_t e = blockIdx.x;  // p * N + t
+    const int p = (int)(e / N);
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const size_t DD = (size_t)D * D;
+    const double* Ae = A + e * DD;
+    const double* Se = S + e * DD;
+    const double* Pe = Psi + e * DD;
+    const double* Ee = Edf + e * DD;
+    const double* SI = SigInv + (size_t)p * sig_stride;
+    for (int q = tid; q < (int)DD; q += nth) {
+        const int o = (q / D) * LD + (q % D);
+        Xm[o] = Ae[q];
+        Sm[o] = Se[q];
+    }
+    if (tid < D) {
+        mv[tid] = m[e * D + tid];
+        lv[tid] = lam[e * D + tid];
+    }
+    __syncthreads();
+    if (tid < D) {
+        double am = 0.0;
+        for (int k = 0; k < D; ++k) am = fma(Xm[tid * LD + k], mv[k], am);
+        uv[tid] = -Ef[e * D + tid] - am + b[e * D + tid];
+    }
+    __syncthreads();
+    if (tid < D) {
+        double d;
+        if (sig_diag) {
+            d = uv[tid] * SI[(size_t)tid * D + tid];
+        } else {
+            d = 0.0;
+            for (int i = 0; i < D; ++i) d = fma(uv[i], SI[(size_t)tid * D + i], d);
+        }
+        dbv[tid] = d;
+        gLb[e * D + tid] = dt * (d + lv[tid]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < D; ++i) {
+            s1 = fma(dbv[i], mv[i], s1);
+            s2 = fma(lv[i], mv[i], s2);
+        }
+        sc[0] = s1;
+        sc[1] = s2;
+    }
+    // X = SigInv (Edf + A) - 2 Psi
+    if (sig_diag) {
+        for (int q = tid; q < (int)DD; q += nth) {
+            const int i = q / D, o = i * LD + (q % D);
+            Xm[o] = SI[(size_t)i * D + i] * (Ee[q] + Xm[o]) - 2.0 * Pe[q];
+        }
+    } else {
+        for (int q = tid; q < (int)DD; q += nth) {
+            const int o = (q / D) * LD + (q % D);
+            Ym[o] = Ee[q] + Xm[o];
+        }
+        __syncthreads();
+        for (int q = tid; q < (int)DD; q += nth) {
+            const int i = q / D, j = q % D;
+            double s = 0.0;
+            for (int k = 0; k < D; ++k) s = fma(SI[(size_t)i * D + k], Ym[k * LD + j], s);
+            Xm[i * LD + j] = s - 2.0 * Pe[q];
+        }
+    }
+    __syncthreads();
+    const int ntj = (D + GJ - 1) / GJ, nti = (D + GI - 1) / GI;
+    if (tid < nti * ntj) {
+        const int i0 = (tid / ntj) * GI, j0 = (tid % ntj) * GJ;
+        int ri[GI], cj[GJ];
+#pragma unroll
+        for (int a = 0; a < GI; ++a) ri[a] = (i0 + a < D ? i0 + a : D - 1) * LD;
+#pragma unroll
+        for (int c = 0; c < GJ; ++c) cj[c] = (j0 + c < D ? j0 + c : D - 1);
+        double acc[GI][GJ] = {};
+        for (int k = 0; k < D; ++k) {
+            double xv[GI], sv[GJ];
+#pragma unroll
+            for (int a = 0; a < GI; ++a) xv[a] = Xm[ri[a] + k];
+#pragma unroll
+            for (int c = 0; c < GJ; ++c) sv[c] = Sm[k * LD + cj[c]];
+#pragma unroll
+            for (int a = 0; a < GI; ++a)
+#pragma unroll
+                for (int c = 0; c < GJ; ++c) acc[a][c] = fma(xv[a], sv[c], acc[a][c]);
+        }
+        const double s1 = sc[0], s2 = sc[1];
+#pragma unroll
+        for (int a = 0; a < GI; ++a)
+#pragma unroll
+            for (int c = 0; c < GJ; ++c) {
+                const int i = i0 + a, j = j0 + c;
+                if (i < D && j < D) {
+                    double corr;
+                    if (flags & VGPA_GRAD_OUTER) corr = dbv[i] * mv[j] + lv[i] * mv[j];
+                    else corr = s1 + s2;
+                    gLA[e * DD + (size_t)i * D + j] = dt * (acc[a][c] - corr);
+                }
+            }
+    }
+}
+
+// core/gradL_Ab.py:85-106.
+__global__ void grad_assemble_1d_kernel(size_t total, int N, const double* __restrict__ A, const double* __restrict__ b,
+                                        const double* __restrict__ m, const double* __restrict__ S,
+                                        const double* __restrict__ lam, const double* __restrict__ Psi,
+                                        const double* __restrict__ Ef, const double* __restrict__ Edf,
+                                        const double* __restrict__ SigInv, int sig_stride, double dt,
+                                        double* __restrict__ gLA, double* __restrict__ gLb) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e / N);
+    const double SI = SigInv[(size_t)p * sig_stride];
+    const double db = SI * (-Ef[e] - A[e] * m[e] + b[e]);
+    const double dA = SI * (Edf[e] + A[e]) * S[e] - db * m[e];
+    gLA[e] = dt * (dA - lam[e] * m[e] - 2.0 * Psi[e] * S[e]);
+    gLb[e] = dt * (db + lam[e]);
+}
+
+int tile_threads(int D) {
+    const int ntiles = ((D + GI - 1) / GI) * ((D + GJ - 1) / GJ);
+    int n = ntiles > D ? ntiles : D;
+    n = vgpa::round_up(n, 64);
+    return n < 64 ? 64 : n;
+}
+
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+extern "C" int vgpa_reduce_energy(int P, int N, int C, const double* x, const double* w, double scale,
+                                  double* out, void* stream) {
+    VGPA_REQUIRE(P >= 0 && N >= 1 && C >= 1 && C <= 256, "vgpa_reduce_energy: bad sizes P=%d N=%d C=%d", P, N, C);
+    VGPA_REQUIRE(x && w && out, "vgpa_reduce_energy: null pointer argument");
+    if (P == 0) return VGPA_OK;
+    hipLaunchKernelGGL(reduce_energy_kernel, dim3(P), dim3(256), 0, vgpa::as_stream(stream), N, C, x, w, scale, out);
+    return vgpa::check_launch("vgpa_reduce_energy");
+}
+
+extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m, const double* S,
+                              const int* obs_idx, const double* obsY, int obsY_stride, const double* H,
+                              const double* Ri, const double* Qi, double logconst, double* Eobs,
+                              double* dEobs_dm, double* jumpS, void* stream) {
+    VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1 && M >= 0, "vgpa_obs_terms: bad sizes P=%d N=%d D=%d M=%d", P, N, D, M);
+    VGPA_REQUIRE(d == D, "vgpa_obs_terms: observation dimension d=%d must equal D=%d", d, D);
+    VGPA_REQUIRE(m && S && (M == 0 || (obs_idx && obsY)) && H && Ri && Eobs && dEobs_dm, "vgpa_obs_terms: null pointer argument");
+    VGPA_REQUIRE(D == 1 || Qi, "vgpa_obs_terms: Qi is required for D > 1");
+    VGPA_REQUIRE(obsY_stride == 0 || obsY_stride == M * d, "vgpa_obs_terms: obsY_stride must be 0 or M*d");
+    if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_obs_terms: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
+    if (P == 0) return VGPA_OK;
+    hipStream_t st = vgpa::as_stream(stream);
+    hipError_t me = hipMemsetAsync(dEobs_dm, 0, sizeof(double) * (size_t)P * N * D, st);
+    if (me != hipSuccess) return vgpa::fail(VGPA_ELAUNCH, "vgpa_obs_terms: memset: %s", hipGetErrorString(me));
+    if (D == 1) {
+        const int bs = 64, grid = (P + bs - 1) / bs;
+        hipLaunchKernelGGL(obs_terms_1d_kernel, dim3(grid), dim3(bs), 0, st, P, N, M, m, S, obs_idx, obsY,
+                           obsY_stride, H, Ri, logconst, Eobs, dEobs_dm, jumpS);
+    } else {
+        const size_t lds = sizeof(double) * 2 * D;
+        hipLaunchKernelGGL(obs_terms_nd_kernel, dim3(P), dim3(64), lds, st, N, D, M, m, S, obs_idx, obsY,
+                           obsY_stride, H, Ri, Qi, logconst, Eobs, dEobs_dm, jumpS);
+    }
+    return vgpa::check_launch("vgpa_obs_terms");
+}
+
+extern "C" int vgpa_kl0(int P, int D, const double* m0, const double* S0, const double* mu0, int mu0_stride,
+                        const double* tau0, int tau0_stride, int m0_is_row, double* KL0, void* stream) {
+    VGPA_REQUIRE(P >= 0 && D >= 1, "vgpa_kl0: bad sizes P=%d D=%d", P, D);
+    VGPA_REQUIRE(m0 && S0 && mu0 && tau0 && KL0, "vgpa_kl0: null pointer argument");
+    VGPA_REQUIRE(mu0_stride == 0 || mu0_stride == D, "vgpa_kl0: mu0_stride must be 0 or D");
+    VGPA_REQUIRE(tau0_stride == 0 || tau0_stride == D * D, "vgpa_kl0: tau0_stride must be 0 or D*D");
+    if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_kl0: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
+    if (P == 0) return VGPA_OK;
+    hipStream_t st = vgpa::as_stream(stream);
+    if (D == 1) {
+        const int bs = 64, grid = (P + bs - 1) / bs;
+        hipLaunchKernelGGL(kl0_1d_kernel, dim3(grid), dim3(bs), 0, st, P, m0, S0, mu0, mu0_stride, tau0, tau0_stride, KL0);
+    } else {
+        const size_t lds = sizeof(double) * ((size_t)4 * D * (D + 1) + D);
+        allow_lds(kl0_nd_kernel, lds);
+        hipLaunchKernelGGL(kl0_nd_kernel, dim3(P), dim3(64), lds, st, D, m0, S0, mu0, mu0_stride, tau0, tau0_stride,
+                           m0_is_row, KL0);
+    }
+    return vgpa::check_launch("vgpa_kl0");
+}
+
+extern "C" int vgpa_grad_assemble(int P, int N, int D, const double* A, const double* b, const double* m,
+                                  const double* S, const double* lam, const double* Psi, const double* Ef,
+                                  const double* Edf, const double* SigInv, int sig_stride, double dt, int flags,
+                                  double* gLA, double* gLb, void* stream) {
+    VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_grad_assemble: bad sizes P=%d N=%d D=%d", P, N, D);
+    VGPA_REQUIRE(A && b && m && S && lam && Psi && Ef && Edf && SigInv && gLA && gLb, "vgpa_grad_assemble: null pointer argument");
+    VGPA_REQUIRE(sig_stride == 0 || sig_stride == D * D, "vgpa_grad_assemble: sig_stride must be 0 or D*D");
+    VGPA_REQUIRE((size_t)P * N < 0x7fffffffull, "vgpa_grad_assemble: P*N too large");
+    if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_grad_assemble: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
+    const size_t total = (size_t)P * N;
+    if (total == 0) return VGPA_OK;
+    hipStream_t st = vgpa::as_stream(stream);
+    if (D == 1) {
+        const int bs = 256;
+        hipLaunchKernelGGL(grad_assemble_1d_kernel, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, total, N,
+                           A, b, m, S, lam, Psi, Ef, Edf, SigInv, sig_stride, dt, gLA, gLb);
+    } else {
+        const int sig_diag = (flags & VGPA_GRAD_SIGINV_DIAG) ? 1 : 0;
+        const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 4 * D + 2);
+        allow_lds(grad_assemble_nd_kernel, lds);
+        hipLaunchKernelGGL(grad_assemble_nd_kernel, dim3((unsigned)total), dim3(tile_threads(D)), lds, st, N, D, A, b, m,
+                           S, lam, Psi, Ef, Edf, SigInv, sig_stride, sig_diag, dt, flags, gLA, gLb);
+    }
+    return vgpa::check_launch("vgpa_grad_assemble");
+}

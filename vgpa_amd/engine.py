@@ -1,0 +1,417 @@
+"""Device-resident evaluation of the variational free energy and its gradient.
+
+Everything here works on float64 torch tensors that live on the GPU, with a
+leading batch axis P of independent problems, and calls the HIP kernels of
+``libvgpa_hip.so`` through ctypes (``vgpa_amd._lib``).  PyTorch is used only to
+own device memory, to pick the HIP stream, and for O(P) / O(D^2) glue (adding
+the three energy terms, scaling hyper-parameter gradients).  There is no CPU
+path: without a HIP device every call raises.
+
+The pipeline of one evaluation (reference: core/varFreeEnergy.py:80-111,
+core/gradL_Ab.py:156-180):
+
+    fwd_scan -> obs_terms -> esde -> reduce_energy -> bwd_scan -> kl0 -> F
+    grad_assemble -> dL/dA, dL/db
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+
+F64 = torch.float64
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("vgpa_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(x, shape=None):
+    """Host array / scalar / tensor -> contiguous float64 device tensor."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=device(), dtype=F64)
+    else:
+        a = np.asarray(x, dtype=np.float64)
+        if not (a.flags.writeable and a.flags.c_contiguous):
+            a = np.array(a, dtype=np.float64, order="C", copy=True)
+        t = torch.from_numpy(a).to(device())
+    if shape is not None:
+        t = t.reshape(shape)
+    return t.contiguous()
+
+
+def _p(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "kernel operands must be contiguous device tensors"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def method_id(method):
+    """core/fwd_ode.py:57-82: case-insensitive name, ValueError otherwise."""
+    try:
+        return _lib.METHODS[str(method).upper()]
+    except KeyError:
+        raise ValueError("Unknown method of integration") from None
+
+
+def trapz_weights(N, idx=None):
+    """Weights w with mytrapz(f, dt, idx) == dt * sum_t w[t] f[t]
+    (auxiliary/numerical.py:231-284): trapezoid rule on each segment [f, l)
+    between consecutive observation indices; the sample at l is not part of the
+    segment and nothing from idx[-1] on is integrated."""
+    w = np.zeros(N, dtype=np.float64)
+    if idx is None:
+        segs = [(0, N)]
+    else:
+        segs, f = [], 0
+        for l in np.asarray(idx).reshape(-1):
+            segs.append((f, int(l)))
+            f = int(l)
+    for f, l in segs:
+        f, l = max(f, 0), min(l, N)
+        if l - f >= 2:
+            w[f:l] += 1.0
+            w[f] -= 0.5
+            w[l - 1] -= 0.5
+    return w
+
+
+@dataclass
+class Problem:
+    """Everything that stays fixed while A(t), b(t) change: sizes, integrator,
+    noise, drift parameters, observations, prior and initial moments.  Arrays are
+    device tensors; parameter arrays are either shared by all P problems (stride 0)
+    or carry a leading P axis."""
+    system: int
+    P: int
+    N: int
+    D: int
+    dt: float
+    method: int
+    Sigma: torch.Tensor            # (D,D) or (P,D,D); 1-D: (1,) or (P,)
+    SigInv: torch.Tensor           # same shape
+    sig_inv_diag: torch.Tensor     # (D,) or (P,D)
+    sig_is_diag: bool
+    theta: torch.Tensor            # (n_theta,) or (P,n_theta)
+    m0: torch.Tensor               # (P,D)
+    S0: torch.Tensor               # (P,D,D); 1-D: (P,)
+    m0_is_row: bool
+    mu0: torch.Tensor              # (D,) or (P,D)
+    tau0: torch.Tensor             # (D,D) or (P,D,D)
+    obs_idx: torch.Tensor          # (M,) int32
+    obs_flag: torch.Tensor         # (N,) int32
+    obsY: torch.Tensor             # (M,d) or (P,M,d)
+    H: torch.Tensor                # (D,d)
+    Ri: torch.Tensor               # (d,d) "Ri" of chol_inv(R): inv(chol) inv(chol)'
+    Qi: torch.Tensor               # (d,d) inv(chol(R))
+    logconst: float                # M (d log 2pi + log det R)
+    w: torch.Tensor                # (N,) trapezoid weights
+    fun: Optional[object] = None   # user energy function evaluated on the host (system < 0)
+    sde_struct: Optional[dict] = None
+    kl0_cache: Optional[torch.Tensor] = field(default=None, repr=False)
+
+    @property
+    def M(self):
+        return int(self.obs_idx.numel())
+
+
+def _chol_inv_host(R):
+    """(Ri, Qi) of auxiliary/numerical.py:10-48 for the observation noise (a
+    constant of the run): Qi = inv(chol(R)), Ri = Qi Qi'."""
+    R = np.asarray(R, dtype=np.float64)
+    if R.ndim == 1:
+        R = np.diag(R)
+    Qi = np.linalg.inv(np.linalg.cholesky(R))
+    return Qi.dot(Qi.T), Qi
+
+
+def make_problem(system, sde, m0, S0, P=1, theta=None, fun=None):
+    """Build a Problem from the reference's ``sde_struct`` dictionary (keys as in
+    lorenz-96-ut.ipynb cell 3) and the initial moments.  ``theta`` may override
+    sde['theta'] with a (P, n_theta) array for a parameter grid; m0 / S0 may carry
+    a leading P axis."""
+    D, N = int(sde["D"]), int(sde["N"])
+    dt = float(sde["dt"])
+    method = method_id(sde.get("ode_method", "EULER"))
+    if D > _lib.MAX_D:
+        raise _lib.VgpaError(f"D={D} exceeds the largest supported state dimension {_lib.MAX_D}")
+    obs_idx = np.asarray(sde["obsX"]).reshape(-1).astype(np.int64)
+    if obs_idx.size and (obs_idx.min() < 0 or obs_idx.max() >= N):
+        raise IndexError("observation index out of range")
+    obs_flag = np.zeros(N, dtype=np.int32)
+    obs_flag[obs_idx] = 1
+    obsY = np.asarray(sde["obsY"], dtype=np.float64)
+    th = np.asarray(sde["theta"] if theta is None else theta, dtype=np.float64)
+    mu0 = np.asarray(sde["px0"]["mu0"], dtype=np.float64)
+    tau0 = np.asarray(sde["px0"]["tau0"], dtype=np.float64)
+    m0a = np.asarray(m0.cpu() if isinstance(m0, torch.Tensor) else m0, dtype=np.float64)
+    S0a = np.asarray(S0.cpu() if isinstance(S0, torch.Tensor) else S0, dtype=np.float64)
+    if D == 1:
+        Sigma = np.asarray(sde["Sig"], dtype=np.float64).reshape(-1)
+        SigInv = 1.0 / Sigma
+        sid = SigInv
+        sig_is_diag = True
+        R = float(np.asarray(sde["Rig"]).reshape(-1)[0])
+        Ri, Qi = np.array([[1.0 / R]]), np.array([[1.0 / np.sqrt(R)]])
+        H = np.asarray(sde["H"], dtype=np.float64).reshape(1, 1)
+        d = 1
+        logconst = obs_idx.size * (_LOG2PI + np.log(R))
+        obsY = obsY.reshape((-1, obs_idx.size, 1)) if obsY.size != obs_idx.size else obsY.reshape(obs_idx.size, 1)
+        th = th.reshape(-1, 1) if th.size > 1 else th.reshape(1)
+        m0_is_row = False
+        m0a = np.broadcast_to(m0a.reshape(-1, 1) if m0a.size > 1 else m0a.reshape(1, 1), (P, 1))
+        S0a = np.broadcast_to(S0a.reshape(-1) if S0a.size > 1 else S0a.reshape(1), (P,))
+        mu0 = mu0.reshape(-1)
+        tau0 = tau0.reshape(-1)
+    else:
+        Sigma = np.asarray(sde["Sig"], dtype=np.float64)
+        SigInv = np.linalg.inv(Sigma)                      # core/gradL_Ab.py:137
+        sid = np.diagonal(SigInv, axis1=-2, axis2=-1).copy()
+        sig_is_diag = bool(np.count_nonzero(SigInv - sid[..., None] * np.eye(D)) == 0)
+        R = np.asarray(sde["Rig"], dtype=np.float64)
+        Ri, Qi = _chol_inv_host(R)
+        H = np.asarray(sde["H"], dtype=np.float64)
+        d = obsY.shape[-1]
+        Rm = np.diag(R) if R.ndim == 1 else R
+        logconst = obs_idx.size * (d * _LOG2PI + 2.0 * np.sum(np.log(np.linalg.cholesky(Rm).diagonal())))
+        m0_is_row = bool(P == 1 and m0a.ndim == 2 and m0a.shape == (1, D))
+        m0a = np.broadcast_to(m0a.reshape(-1, D), (P, D))
+        S0a = np.broadcast_to(S0a.reshape(-1, D, D), (P, D, D))
+    prob = Problem(
+        system=system, P=P, N=N, D=D, dt=dt, method=method,
+        Sigma=to_dev(Sigma), SigInv=to_dev(SigInv), sig_inv_diag=to_dev(sid), sig_is_diag=sig_is_diag,
+        theta=to_dev(th), m0=to_dev(m0a), S0=to_dev(S0a), m0_is_row=m0_is_row,
+        mu0=to_dev(mu0), tau0=to_dev(tau0),
+        obs_idx=torch.from_numpy(obs_idx.astype(np.int32)).to(device()),
+        obs_flag=torch.from_numpy(obs_flag).to(device()),
+        obsY=to_dev(obsY), H=to_dev(H), Ri=to_dev(Ri), Qi=to_dev(Qi), logconst=float(logconst),
+        w=to_dev(trapz_weights(N, obs_idx)), fun=fun, sde_struct=sde)
+    return prob
+
+
+_LOG2PI = 1.8378770664093453   # core/likelihood.py@10
+
+
+# ---------------------------------------------------------------------------
+# thin wrappers, one per C entry point (device tensors in, device tensors out)
+# ---------------------------------------------------------------------------
+def _mat_shape(P, N, D):
+    return ((P, N), (P, N)) if D == 1 else ((P, N, D), (P, N, D, D))
+
+
+def fwd_scan(method, A, b, m0, S0, Sigma, dt):
+    """vgpa_fwd_scan.  A (P,N,D,D) / (P,N) -> m, S."""
+    P, N = A.shape[0], A.shape[1]
+    D = 1 if A.dim() == 2 else A.shape[-1]
+    vs, ms = _mat_shape(P, N, D)
+    m = torch.empty(vs, dtype=F64, device=A.device)
+    S = torch.empty(ms, dtype=F64, device=A.device)
+    sstride = _par_stride(Sigma, P, D * D)
+    call("vgpa_fwd_scan", method, P, N, D, _p(A), _p(b), _p(m0), _p(S0), _p(Sigma), sstride, float(dt),
+         _p(m), _p(S), _stream())
+    return m, S
+
+
+def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, jumpS=None):
+    """vgpa_bwd_scan -> lam, Psi."""
+    P, N = A.shape[0], A.shape[1]
+    D = 1 if A.dim() == 2 else A.shape[-1]
+    lam = torch.empty_like(dEdm)
+    Psi = torch.empty_like(dEdS)
+    jstride = 0
+    if jumpS is not None and jumpS.numel() == P * D * D and P > 1:
+        jstride = D * D
+    call("vgpa_bwd_scan", method, P, N, D, _p(A), _p(dEdm), _p(dEdS), _p(dEobs_dm), _p(dEobs_dS),
+         _p(obs_flag), _p(jumpS), jstride, float(dt), _p(lam), _p(Psi), _stream())
+    return lam, Psi
+
+
+def _par_stride(t, P, per_problem_numel):
+    """0 when a parameter tensor is shared, else its per-problem element count."""
+    return per_problem_numel if (t.numel() == P * per_problem_numel and P > 1) else 0
+
+
+def esde(system, A, b, m, S, sig_inv_diag, theta, want_edf=True, want_hyper=True):
+    """vgpa_esde -> dict(Esde_t, Ef, Edf, dEdm, dEdS, dth_t, dSig_t, status)."""
+    P, N = A.shape[0], A.shape[1]
+    D = 1 if A.dim() == 2 else A.shape[-1]
+    vs, ms = _mat_shape(P, N, D)
+    dev = A.device
+    n_theta = 3 if system in (_lib.SYS_L63, _lib.SYS_L63_UT) else 1
+    out = dict(
+        Esde_t=torch.empty((P, N), dtype=F64, device=dev),
+        Ef=torch.empty(vs, dtype=F64, device=dev),
+        Edf=torch.empty(ms, dtype=F64, device=dev) if (want_edf or D == 1) else None,
+        dEdm=torch.empty(vs, dtype=F64, device=dev),
+        dEdS=torch.empty(ms, dtype=F64, device=dev),
+        dth_t=torch.empty(vs, dtype=F64, device=dev) if want_hyper else None,
+        dSig_t=torch.empty(vs, dtype=F64, device=dev) if (want_hyper and D > 1) else None,
+        status=torch.zeros((P, N), dtype=torch.int32, device=dev),
+    )
+    call("vgpa_esde", system, P, N, D, _p(A), _p(b), _p(m), _p(S),
+         _p(sig_inv_diag), _par_stride(sig_inv_diag, P, D),
+         _p(theta), _par_stride(theta, P, n_theta),
+         _p(out["Esde_t"]), _p(out["Ef"]), _p(out["Edf"]), _p(out["dEdm"]), _p(out["dEdS"]),
+         _p(out["dth_t"]), _p(out["dSig_t"]), _p(out["status"]), _stream())
+    return out
+
+
+def reduce_energy(x, w, scale):
+    """vgpa_reduce_energy: x (P,N) or (P,N,C) -> (P,) or (P,C)."""
+    P, N = x.shape[0], x.shape[1]
+    C = 1 if x.dim() == 2 else x.shape[2]
+    out = torch.empty((P,) if x.dim() == 2 else (P, C), dtype=F64, device=x.device)
+    call("vgpa_reduce_energy", P, N, C, _p(x), _p(w), float(scale), _p(out), _stream())
+    return out
+
+
+def obs_terms(prob, m, S):
+    """vgpa_obs_terms -> Eobs (P,), dEobs_dm (like m), jumpS (D,D)."""
+    P, N, D = prob.P, prob.N, prob.D
+    Eobs = torch.empty((P,), dtype=F64, device=m.device)
+    dm = torch.empty_like(m)
+    jumpS = torch.empty((D, D) if D > 1 else (1,), dtype=F64, device=m.device)
+    d = prob.obsY.shape[-1]
+    ystride = prob.M * d if (prob.obsY.dim() == 3 and P > 1) else 0
+    call("vgpa_obs_terms", P, N, D, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
+         _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(Eobs), _p(dm), _p(jumpS), _stream())
+    return Eobs, dm, jumpS
+
+
+def kl0(prob):
+    """vgpa_kl0 -> KL0 (P,).  Independent of A, b: cached on the Problem."""
+    if prob.kl0_cache is None:
+        P, D = prob.P, prob.D
+        out = torch.empty((P,), dtype=F64, device=prob.m0.device)
+        call("vgpa_kl0", P, D, _p(prob.m0), _p(prob.S0), _p(prob.mu0), _par_stride(prob.mu0, P, D),
+             _p(prob.tau0), _par_stride(prob.tau0, P, D * D), int(prob.m0_is_row), _p(out), _stream())
+        prob.kl0_cache = out
+    return prob.kl0_cache
+
+
+def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False):
+    """vgpa_grad_assemble -> gLA (like A), gLb (like b), already times dt."""
+    P, N, D = prob.P, prob.N, prob.D
+    gLA = torch.empty_like(A)
+    gLb = torch.empty_like(b)
+    flags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
+    call("vgpa_grad_assemble", P, N, D, _p(A), _p(b), _p(m), _p(S), _p(lam), _p(Psi), _p(Ef), _p(Edf),
+         _p(prob.SigInv), _par_stride(prob.SigInv, P, D * D), float(prob.dt), flags, _p(gLA), _p(gLb), _stream())
+    return gLA, gLb
+
+
+# ---------------------------------------------------------------------------
+# the evaluation
+# ---------------------------------------------------------------------------
+def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hyper=True):
+    """The ``energy_mode`` contract on device: per-step kernel + time reductions.
+    Returns a dict with Esde (P,), Ef, Edf, dEdm, dEdS, dth, dSig, status."""
+    D = 1 if A.dim() == 2 else A.shape[-1]
+    out = esde(system, A, b, m, S, sig_inv_diag, theta, True, want_hyper)
+    out["Esde"] = reduce_energy(out["Esde_t"], w, dt)
+    if want_hyper:
+        tr_th = reduce_energy(out["dth_t"], w, dt)
+        if D == 1:
+            k = 1.0 if system == _lib.SYS_OU else 4.0
+            out["dth"] = k * SigInv.reshape(-1) * tr_th                      # sys_ornstein_uhlenbeck.py:153
+            out["dSig"] = -SigInv.reshape(-1) * out["Esde"]                  # :156
+        else:
+            out["dth"] = sig_inv_diag * tr_th                                # sys_lorenz_96_ut.py:253
+            tr_sig = reduce_energy(out["dSig_t"], w, dt)
+            out["dSig"] = -0.5 * SigInv @ torch.diag_embed(tr_sig) @ SigInv  # :256
+    return out
+
+
+def _host_energy(prob, A, b, m, S):
+    """A user-supplied ``fun(A, b, m, S, sde_struct)`` (the reference's plug-in
+    point, core/varFreeEnergy.py:93) is Python code: it runs on the host on copies
+    of the device arrays, one problem at a time."""
+    outs = []
+    for p in range(prob.P):
+        r = prob.fun(A[p].cpu().numpy(), b[p].cpu().numpy(), _host_vec(m[p], prob.D), _host_vec(S[p], prob.D),
+                     prob.sde_struct)
+        outs.append(r)
+    stack = lambda k, shp: to_dev(np.stack([np.asarray(o[k], dtype=np.float64).reshape(shp) for o in outs]))  # noqa
+    N, D = prob.N, prob.D
+    vs, ms = ((N,), (N,)) if D == 1 else ((N, D), (N, D, D))
+    return dict(Esde=stack(0, ()), Ef=stack(1, vs), Edf=stack(2, ms), dEdm=stack(3, vs), dEdS=stack(4, ms),
+                dth=None, dSig=None, status=torch.zeros((prob.P, N), dtype=torch.int32, device=A.device))
+
+
+def _host_vec(t, D):
+    a = t.cpu().numpy()
+    return a.reshape(-1, 1) if D == 1 else a
+
+
+@dataclass
+class State:
+    """Everything one free-energy evaluation produces (device tensors)."""
+    F: torch.Tensor
+    KL0: torch.Tensor
+    Eobs: torch.Tensor
+    Esde: torch.Tensor
+    m: torch.Tensor
+    S: torch.Tensor
+    lam: torch.Tensor
+    Psi: torch.Tensor
+    Ef: torch.Tensor
+    Edf: torch.Tensor
+    dEdm: torch.Tensor
+    dEdS: torch.Tensor
+    dEobs_dm: torch.Tensor
+    jumpS: torch.Tensor
+    status: torch.Tensor
+    dth: Optional[torch.Tensor] = None
+    dSig: Optional[torch.Tensor] = None
+
+
+def free_energy(prob, A, b, want_hyper=False):
+    """core/varFreeEnergy.py:80-111 for a batch: returns a State with F (P,)."""
+    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt)
+    Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
+    if prob.system < 0:
+        en = _host_energy(prob, A, b, m, S)
+    else:
+        en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w,
+                          prob.dt, want_hyper)
+    lam, Psi = bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
+                        obs_flag=prob.obs_flag, jumpS=jumpS)
+    KL0 = kl0(prob)
+    F = KL0 + Eobs + en["Esde"]
+    return State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"],
+                 Edf=en["Edf"], dEdm=en["dEdm"], dEdS=en["dEdS"], dEobs_dm=dEobs_dm, jumpS=jumpS,
+                 status=en["status"], dth=en.get("dth"), dSig=en.get("dSig"))
+
+
+def gradient(prob, A, b, st, outer=False):
+    """core/gradL_Ab.py:156-180 for a batch: (gLA, gLb), already times dt."""
+    return grad_assemble(prob, A, b, st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf, outer=outer)
+
+
+def check_status(status):
+    """Raise like the reference when a covariance lost positive definiteness
+    (auxiliary/numerical.py:199-202 lets LinAlgError escape when the diagonal
+    fallback fails too)."""
+    if status is None or status.numel() == 0:
+        return
+    bad = 0
+    for bit in (_lib.ST_CHOL_FAILED, _lib.ST_UNSUPPORTED):
+        if bool((status & bit).any().item()):
+            bad |= bit
+    if bad & _lib.ST_CHOL_FAILED:
+        raise np.linalg.LinAlgError("Matrix is not positive definite")
+    if bad & _lib.ST_UNSUPPORTED:
+        raise np.linalg.LinAlgError(
+            "S(t) is not positive definite; the diagonal sigma-point fallback is not available on the "
+            "device for this system")
