@@ -587,6 +587,16 @@ __global__ void __launch_bounds__(64) esde_l96_ut_kernel(EsdeArgs a) {
     }
 }
 
+#include "esde_l96_tiled.h"
+
+template <int D>
+void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
+    const size_t lds = sizeof(double) * L96Tiled<D>::LDS_DOUBLES;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_ut_tiled_kernel<D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(esde_l96_ut_tiled_kernel<D>, dim3((unsigned)total), dim3(256), lds, st, a);
+}
+
 int launch_esde(int system, const EsdeArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.P * a.N;
     if (total == 0) return VGPA_OK;
@@ -606,6 +616,8 @@ int launch_esde(int system, const EsdeArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(esde_l63_ut_kernel, dim3(grid), dim3(bs), 0, st, a);
             break;
         case VGPA_SYS_L96_UT: {
+            if (a.D == 40) { launch_l96_tiled<40>(a, total, st); break; }
+            if (a.D == 16) { launch_l96_tiled<16>(a, total, st); break; }
             const size_t lds = sizeof(double) * ((size_t)4 * a.D * (a.D + 1) + 5 * a.D);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_ut_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
