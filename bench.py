@@ -114,9 +114,10 @@ def main():
     prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
 
     ev_pairs = []
+    sym_bwd = prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D)
 
     def step(timed):
-        m, S = engine.fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt)
+        m, S = engine.fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
         Eobs, dEobs_dm, jumpS = engine.obs_terms(prob, m, S)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -127,7 +128,7 @@ def main():
             ev_pairs.append((e0, e1))
         Esde = engine.reduce_energy(en["Esde_t"], prob.w, prob.dt)
         lam, Psi = engine.bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-                                   obs_flag=prob.obs_flag, jumpS=jumpS)
+                                   obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym_bwd)
         F = engine.kl0(prob) + Eobs + Esde
         gLA, gLb = engine.grad_assemble(prob, A, b, m, S, lam, Psi, en["Ef"], en["Edf"])
         return F, gLA, gLb, en["status"]

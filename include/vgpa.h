@@ -62,6 +62,13 @@ extern "C" {
                                     (core/gradL_Ab.py:167,170).  Off by default. */
 #define VGPA_GRAD_SIGINV_DIAG 2  /* SigInv is diagonal: only its diagonal is read */
 
+/* scan flags */
+#define VGPA_SCAN_SYMMETRIC 1    /* the caller guarantees bitwise symmetric matrix
+                                    inputs (forward: S0 and Sigma; backward: every
+                                    dEsde_dS[t] and every jump).  The scan then forms
+                                    one matrix product per stage instead of two; the
+                                    result is bit-for-bit that of the general path. */
+
 /* largest state dimension the n-D kernels accept */
 #define VGPA_MAX_D 60
 
@@ -73,12 +80,13 @@ const char* vgpa_last_error_string(void);
  * dt, method)` and its eight integrators (euler_nD :87, euler_1D :135, heun_nD
  * :181, heun_1D :247, rk2_nD :311, rk2_1D :367, rk4_nD :426, rk4_1D :493).
  *   A (P,N,D,D)  b (P,N,D)  m0 (P,D)  S0 (P,D,D)  Sigma (D,D) [sigma_stride]
+ *   flags: VGPA_SCAN_SYMMETRIC or 0.
  *   -> m_out (P,N,D), S_out (P,N,D,D);  row 0 holds (m0, S0).
  */
 int vgpa_fwd_scan(int method, int P, int N, int D,
                   const double* A, const double* b,
                   const double* m0, const double* S0,
-                  const double* Sigma, int sigma_stride, double dt,
+                  const double* Sigma, int sigma_stride, double dt, int flags,
                   double* m_out, double* S_out, void* stream);
 
 /*
@@ -89,13 +97,14 @@ int vgpa_fwd_scan(int method, int P, int N, int D,
  *   `dEobs_dS` (P,N,D,D), or -- when dEobs_dS is NULL -- `jumpS` (D,D)
  *   [jumpS_stride] added at every row t with obs_flag[t] != 0 (obs_flag is (N)
  *   int32, shared by all problems).  Both NULL means no covariance jumps.
+ *   flags: VGPA_SCAN_SYMMETRIC or 0.
  *   -> lam_out (P,N,D), Psi_out (P,N,D,D); row N-1 is zero.
  */
 int vgpa_bwd_scan(int method, int P, int N, int D,
                   const double* A, const double* dEsde_dm, const double* dEsde_dS,
                   const double* dEobs_dm, const double* dEobs_dS,
                   const int* obs_flag, const double* jumpS, int jumpS_stride,
-                  double dt, double* lam_out, double* Psi_out, void* stream);
+                  double dt, int flags, double* lam_out, double* Psi_out, void* stream);
 
 /*
  * Per-time-step expected SDE energy and its gradients: replaces the loop body of

@@ -39,19 +39,20 @@ def test_header_constants_match_binding():
         assert int(defs["VGPA_SYS_" + k.upper()]) == v
     assert int(defs["VGPA_GRAD_OUTER"]) == _lib.GRAD_OUTER
     assert int(defs["VGPA_GRAD_SIGINV_DIAG"]) == _lib.GRAD_SIGINV_DIAG
+    assert int(defs["VGPA_SCAN_SYMMETRIC"]) == _lib.SCAN_SYMMETRIC
 
 
 def test_bad_arguments_are_rejected_without_a_device():
     from vgpa_amd import _lib
     one = ctypes.c_void_p(8)   # never dereferenced: validation fails first
     with pytest.raises(ValueError, match="Unknown method of integration"):
-        _lib.call("vgpa_fwd_scan", 7, 1, 4, 3, one, one, one, one, one, 0, 0.01, one, one, None)
+        _lib.call("vgpa_fwd_scan", 7, 1, 4, 3, one, one, one, one, one, 0, 0.01, 0, one, one, None)
     with pytest.raises(ValueError, match="Unknown method of integration"):
-        _lib.call("vgpa_bwd_scan", -1, 1, 4, 3, one, one, one, one, None, None, None, 0, 0.01, one, one, None)
+        _lib.call("vgpa_bwd_scan", -1, 1, 4, 3, one, one, one, one, None, None, None, 0, 0.01, 0, one, one, None)
     with pytest.raises(_lib.VgpaError, match="null pointer"):
-        _lib.call("vgpa_fwd_scan", 0, 1, 4, 3, None, one, one, one, one, 0, 0.01, one, one, None)
+        _lib.call("vgpa_fwd_scan", 0, 1, 4, 3, None, one, one, one, one, 0, 0.01, 0, one, one, None)
     with pytest.raises(_lib.VgpaError, match="exceeds VGPA_MAX_D"):
-        _lib.call("vgpa_fwd_scan", 0, 1, 4, 200, one, one, one, one, one, 0, 0.01, one, one, None)
+        _lib.call("vgpa_fwd_scan", 0, 1, 4, 200, one, one, one, one, one, 0, 0.01, 0, one, one, None)
     with pytest.raises(_lib.VgpaError, match="Lorenz-63 needs D == 3"):
         _lib.call("vgpa_esde_l63", 1, 4, 5, one, one, one, one, one, 0, one, 0, one, one, one, one, one,
                   None, None, None, None)

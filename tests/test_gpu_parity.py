@@ -70,7 +70,7 @@ def test_energy_mode_vs_golden(system, fname):
             assert np.asarray(v).shape == np.asarray(g[gk]).shape, n
 
 
-@pytest.mark.parametrize("D", [1, 3, 6, 40])
+@pytest.mark.parametrize("D", [1, 3, 6, 16, 40])
 @pytest.mark.parametrize("method", METHODS)
 def test_scans_vs_oracle_random_inputs(D, method):
     """fwd_ode.solver / bwd_ode.solver on inputs with no special structure
@@ -291,3 +291,35 @@ def test_lorenz96_energy_kernels_vs_oracle(D):
     for n, v, r in zip(names, out, ref[:7]):
         assert relerr(v, r) <= TOL, n
     assert np.array_equal(out[4], np.swapaxes(out[4], 1, 2)) or D not in (16, 40)
+
+
+@pytest.mark.parametrize("D", [6, 16, 40])
+@pytest.mark.parametrize("method", METHODS)
+def test_symmetric_scan_kernels_are_bitwise_the_general_ones(D, method):
+    """With exactly symmetric inputs the one-product-per-stage kernels must return
+    the same bits as the two-product kernels, and both match the oracle."""
+    import torch
+    from vgpa_amd import engine
+    rng = np.random.default_rng(400 + D)
+    N, dt, P = 17, 0.01, 3
+    sym = lambda X: 0.5 * (X + np.swapaxes(X, -1, -2))   # noqa: E731
+    A = 4.0 * np.eye(D)[None, None] + 0.5 * rng.standard_normal((P, N, D, D))
+    b = rng.standard_normal((P, N, D))
+    m0 = rng.standard_normal((P, D))
+    S0 = 0.25 * np.eye(D)[None] + 0.05 * sym(rng.standard_normal((P, D, D)))
+    Sig = 2.0 * np.eye(D) + 0.1 * sym(rng.standard_normal((D, D)))
+    gm, gS = rng.standard_normal((P, N, D)), sym(rng.standard_normal((P, N, D, D)))
+    jm, jS = rng.standard_normal((P, N, D)), sym(rng.standard_normal((P, N, D, D)))
+    mid = engine.method_id(method)
+    d = engine.to_dev
+    m1, S1 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=True)
+    m2, S2 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=False)
+    assert torch.equal(S1, S2) and torch.equal(m1, m2)
+    l1, P1 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, dEobs_dS=d(jS), symmetric=True)
+    l2, P2 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, dEobs_dS=d(jS), symmetric=False)
+    assert torch.equal(P1, P2) and torch.equal(l1, l2)
+    for p in range(P):
+        mr, Sr = orc.fwd_scan(A[p], b[p], m0[p], S0[p], Sig, dt, method)
+        assert relerr(S1[p].cpu().numpy(), Sr) <= TOL and relerr(m1[p].cpu().numpy(), mr) <= TOL
+        lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS[p], dt, method)
+        assert relerr(P1[p].cpu().numpy(), Pr) <= TOL and relerr(l1[p].cpu().numpy(), lr) <= TOL

@@ -25,6 +25,7 @@ SYS_OU, SYS_DW, SYS_L63, SYS_L63_UT, SYS_L96_UT = 0, 1, 2, 3, 4
 SYSTEMS = {"ou": SYS_OU, "dw": SYS_DW, "l63": SYS_L63, "l63_ut": SYS_L63_UT, "l96_ut": SYS_L96_UT}
 ST_CHOL_FALLBACK, ST_CHOL_FAILED, ST_UNSUPPORTED = 1, 2, 4
 GRAD_OUTER, GRAD_SIGINV_DIAG = 1, 2
+SCAN_SYMMETRIC = 1
 MAX_D = 60
 
 _c_int, _c_dbl, _ptr = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
@@ -33,9 +34,10 @@ _ESDE_ARGS = [_c_int, _c_int, _c_int] + [_ptr] * 4 + [_ptr, _c_int, _ptr, _c_int
 
 # name -> argtypes; every function returns int except the two noted below
 SIGNATURES = {
-    "vgpa_fwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl, _ptr, _ptr, _ptr],
-    "vgpa_bwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl,
+    "vgpa_fwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl, _c_int,
                       _ptr, _ptr, _ptr],
+    "vgpa_bwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl,
+                      _c_int, _ptr, _ptr, _ptr],
     "vgpa_esde": [_c_int] + _ESDE_ARGS,
     "vgpa_esde_ou": _ESDE_ARGS,
     "vgpa_esde_dw": _ESDE_ARGS,

@@ -18,5 +18,7 @@ def solver(A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, dt=0.01, method="EULER"):
     Ad = _facade.dev_batch1(A, D, "m")
     gm, jm = _facade.dev_batch1(dEsde_dm, D, "v"), _facade.dev_batch1(dEobs_dm, D, "v")
     gS, jS = _facade.dev_batch1(dEsde_dS, D, "m"), _facade.dev_batch1(dEobs_dS, D, "m")
-    lam, Psi = engine.bwd_scan(mid, Ad, gm, gS, jm, dt, dEobs_dS=jS)
+    sym = D > 1 and all(np.array_equal(x, np.swapaxes(x, -1, -2))
+                        for x in (np.asarray(dEsde_dS), np.asarray(dEobs_dS)))
+    lam, Psi = engine.bwd_scan(mid, Ad, gm, gS, jm, dt, dEobs_dS=jS, symmetric=sym)
     return _facade.host_vec(lam, D), _facade.host_mat(Psi, D)

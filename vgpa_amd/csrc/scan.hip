@@ -5,13 +5,21 @@
 // independent problems (one workgroup per problem for D > 1, one lane per problem
 // for D == 1) and from the D x D matrix products inside a step.
 //
-// n-D layout inside a workgroup: every thread owns one TI x TJ tile of the D x D
+// n-D layout inside a workgroup: every thread owns one 2 x 4 tile of the D x D
 // state (S or Psi) and keeps it, and its Runge-Kutta increments, in registers for
 // the whole scan.  Only the stage input X (what the other threads need for the
 // matrix product) goes through LDS, in two alternating buffers so that one
-// barrier per stage is enough.  A(t) is staged through LDS, prefetched one step
-// ahead into registers; rows are padded by one double so that both row- and
-// column-indexed reads are free of bank conflicts.
+// barrier per stage is enough.  A(t) is staged through LDS and prefetched two
+// steps ahead into registers.
+//
+// Two orthogonal specialisations:
+//   DT   compile-time dimension (40, 16) with an even leading dimension, 16-byte
+//        LDS reads and unrolled product loops; DT = 0 is the run-time-D version.
+//   SYM  the caller guarantees bitwise symmetric inputs (S0, Sigma; or dEsde_dS and
+//        the jumps).  Then -A S - S A' = -(M + M') with M = A S, and
+//        Psi A + A' Psi = Q + Q' with Q = Psi A: one product per stage instead of
+//        two, the transpose going through LDS.  Because the same products are
+//        summed in the same order, the result is bit-for-bit the general one.
 #include "common.h"
 
 namespace {
@@ -20,189 +28,401 @@ constexpr int TI = 2;    // tile rows per thread
 constexpr int TJ = 4;    // tile cols per thread
 constexpr int PRE = 8;   // max A elements a thread stages per step (D*D / nthreads <= 8)
 
+template <int DT_>
 struct NdGeom {
-    int D, LD, MS;        // dimension, padded leading dimension, padded matrix size
+    static constexpr int DT = DT_;
+    int Dr, LDr;          // run-time dimension / leading dimension (DT == 0)
     int nthreads;
     int i0, j0;           // tile origin
     bool has_tile;
     int vi;               // row of the vector state owned by this thread, or -1
+    __device__ __forceinline__ int D() const { return DT > 0 ? DT : Dr; }
+    __device__ __forceinline__ int LD() const { return DT > 0 ? DT + 2 : LDr; }
+    __device__ __forceinline__ int MS() const { return D() * LD(); }
 };
 
-__device__ inline NdGeom make_geom(int D) {
-    NdGeom g;
-    g.D = D;
-    g.LD = D + 1;
-    g.MS = D * g.LD;
+template <int DT>
+__device__ inline NdGeom<DT> make_geom(int D) {
+    NdGeom<DT> g;
+    g.Dr = D;
+    g.LDr = D + 1;
     g.nthreads = blockDim.x;
-    const int ntj = (D + TJ - 1) / TJ;
-    const int nti = (D + TI - 1) / TI;
+    const int ntj = (g.D() + TJ - 1) / TJ;
+    const int nti = (g.D() + TI - 1) / TI;
     const int tile = threadIdx.x;
     g.has_tile = tile < nti * ntj;
     g.i0 = (tile / ntj) * TI;
     g.j0 = (tile % ntj) * TJ;
     const int v = g.nthreads - 1 - (int)threadIdx.x;   // vector rows live on the last D threads
-    g.vi = (v < D) ? v : -1;
+    g.vi = (v < g.D()) ? v : -1;
     return g;
 }
 
 __device__ inline int clampi(int x, int hi) { return x < hi ? x : hi; }
 
-// Copy a dense D x D matrix from global memory into a padded LDS image.
-__device__ inline void load_matrix_lds(const NdGeom& g, const double* __restrict__ src, double* dst) {
-    const int DD = g.D * g.D;
-    for (int e = threadIdx.x; e < DD; e += g.nthreads) dst[(e / g.D) * g.LD + (e % g.D)] = src[e];
+template <class G>
+__device__ inline void load_matrix_lds(const G& g, const double* __restrict__ src, double* dst) {
+    const int D = g.D(), DD = D * D;
+    for (int e = threadIdx.x; e < DD; e += g.nthreads) dst[(e / D) * g.LD() + (e % D)] = src[e];
 }
 
-__device__ inline void prefetch_matrix(const NdGeom& g, const double* __restrict__ src, double pre[PRE]) {
-    const int DD = g.D * g.D;
+// For the compile-time sizes the block has exactly one thread per tile and D*D is
+// a multiple of 2 * nthreads, so the staging loads, tile loads and tile stores
+// below carry no predicates: the compiler can then count outstanding memory
+// operations and wait only for the oldest ones (a predicated load forces a full
+// drain of the prefetch queue at every use).
+template <class G>
+__device__ inline void prefetch_matrix(const G& g, const double* __restrict__ src, double pre[PRE]) {
+    if constexpr (G::DT > 0) {
+        const double2* s2 = reinterpret_cast<const double2*>(src);
 #pragma unroll
-    for (int q = 0; q < PRE; ++q) {
-        const int e = threadIdx.x + q * g.nthreads;
-        pre[q] = (e < DD) ? src[e] : 0.0;
+        for (int q = 0; q < PRE / 2; ++q) {
+            const double2 v = s2[threadIdx.x + q * (G::DT * G::DT / PRE)];
+            pre[2 * q] = v.x;
+            pre[2 * q + 1] = v.y;
+        }
+    } else {
+        const int DD = g.D() * g.D();
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = threadIdx.x + q * g.nthreads;
+            pre[q] = (e < DD) ? src[e] : 0.0;
+        }
     }
 }
 
 // Write the prefetched matrix into `dst` and, when `mid` is non-null, the midpoint
 // 0.5*(other + new) into `mid` (each element is handled by the thread that staged it).
-__device__ inline void commit_matrix(const NdGeom& g, const double pre[PRE], double* dst,
+template <class G>
+__device__ inline void commit_matrix(const G& g, const double pre[PRE], double* dst,
                                      const double* other, double* mid) {
-    const int DD = g.D * g.D;
+    if constexpr (G::DT > 0) {
 #pragma unroll
-    for (int q = 0; q < PRE; ++q) {
-        const int e = threadIdx.x + q * g.nthreads;
-        if (e < DD) {
-            const int o = (e / g.D) * g.LD + (e % g.D);
-            dst[o] = pre[q];
-            if (mid) mid[o] = 0.5 * (other[o] + pre[q]);
+        for (int q = 0; q < PRE / 2; ++q) {
+            const int e = 2 * (threadIdx.x + q * (G::DT * G::DT / PRE));
+            const int o = (e / G::DT) * g.LD() + (e % G::DT);
+            *reinterpret_cast<double2*>(dst + o) = make_double2(pre[2 * q], pre[2 * q + 1]);
+            if (mid) {
+                const double2 ov = *reinterpret_cast<const double2*>(other + o);
+                *reinterpret_cast<double2*>(mid + o) =
+                    make_double2(0.5 * (ov.x + pre[2 * q]), 0.5 * (ov.y + pre[2 * q + 1]));
+            }
+        }
+    } else {
+        const int D = g.D(), DD = D * D;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = threadIdx.x + q * g.nthreads;
+            if (e < DD) {
+                const int o = (e / D) * g.LD() + (e % D);
+                dst[o] = pre[q];
+                if (mid) mid[o] = 0.5 * (other[o] + pre[q]);
+            }
         }
     }
 }
 
-__device__ inline void load_tile(const NdGeom& g, const double* __restrict__ src, double t[TI][TJ]) {
+template <class G>
+__device__ inline void load_tile(const G& g, const double* __restrict__ src, double t[TI][TJ]) {
+    if constexpr (G::DT > 0) {
 #pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int c = 0; c < TJ; ++c) {
-            const int i = g.i0 + a, j = g.j0 + c;
-            t[a][c] = (g.has_tile && i < g.D && j < g.D) ? src[i * g.D + j] : 0.0;
+        for (int a = 0; a < TI; ++a) {
+            const double2* r = reinterpret_cast<const double2*>(src + (g.i0 + a) * G::DT + g.j0);
+            const double2 v0 = r[0], v1 = r[1];
+            t[a][0] = v0.x; t[a][1] = v0.y; t[a][2] = v1.x; t[a][3] = v1.y;
         }
-}
-
-__device__ inline void store_tile_global(const NdGeom& g, double* __restrict__ dst, const double t[TI][TJ]) {
-    if (!g.has_tile) return;
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int c = 0; c < TJ; ++c) {
-            const int i = g.i0 + a, j = g.j0 + c;
-            if (i < g.D && j < g.D) dst[i * g.D + j] = t[a][c];
-        }
-}
-
-__device__ inline void store_tile_lds(const NdGeom& g, double* dst, const double t[TI][TJ]) {
-    if (!g.has_tile) return;
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int c = 0; c < TJ; ++c) {
-            const int i = g.i0 + a, j = g.j0 + c;
-            if (i < g.D && j < g.D) dst[i * g.LD + j] = t[a][c];
-        }
-}
-
-// k = Sig - Am*X - X*Am'   (core/fwd_ode.py:45)
-__device__ inline void fwd_rhs_tile(const NdGeom& g, const double* Am, const double* X,
-                                    const double sig[TI][TJ], double k[TI][TJ]) {
-    if (!g.has_tile) return;
-    int ri[TI], cj[TJ];
-#pragma unroll
-    for (int a = 0; a < TI; ++a) ri[a] = clampi(g.i0 + a, g.D - 1) * g.LD;
-#pragma unroll
-    for (int c = 0; c < TJ; ++c) cj[c] = clampi(g.j0 + c, g.D - 1);
-    double s1[TI][TJ] = {}, s2[TI][TJ] = {};
-    for (int q = 0; q < g.D; ++q) {
-        double a_iq[TI], x_iq[TI], x_qj[TJ], a_jq[TJ];
-#pragma unroll
-        for (int a = 0; a < TI; ++a) { a_iq[a] = Am[ri[a] + q]; x_iq[a] = X[ri[a] + q]; }
-#pragma unroll
-        for (int c = 0; c < TJ; ++c) { x_qj[c] = X[q * g.LD + cj[c]]; a_jq[c] = Am[cj[c] * g.LD + q]; }
+    } else {
+        const int D = g.D();
 #pragma unroll
         for (int a = 0; a < TI; ++a)
 #pragma unroll
             for (int c = 0; c < TJ; ++c) {
-                s1[a][c] = fma(a_iq[a], x_qj[c], s1[a][c]);
-                s2[a][c] = fma(x_iq[a], a_jq[c], s2[a][c]);
+                const int i = g.i0 + a, j = g.j0 + c;
+                t[a][c] = (g.has_tile && i < D && j < D) ? src[i * D + j] : 0.0;
             }
     }
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int c = 0; c < TJ; ++c) k[a][c] = -s1[a][c] - s2[a][c] + sig[a][c];
 }
 
-// k = -G + X*Am + Am'*X   (core/bwd_ode.py:43)
-__device__ inline void bwd_rhs_tile(const NdGeom& g, const double* Am, const double* X,
-                                    const double G[TI][TJ], double k[TI][TJ]) {
-    if (!g.has_tile) return;
-    int ri[TI], ci[TI], cj[TJ];
+template <class G>
+__device__ inline void store_tile_global(const G& g, double* __restrict__ dst, const double t[TI][TJ]) {
+    if constexpr (G::DT > 0) {
 #pragma unroll
-    for (int a = 0; a < TI; ++a) { ci[a] = clampi(g.i0 + a, g.D - 1); ri[a] = ci[a] * g.LD; }
-#pragma unroll
-    for (int c = 0; c < TJ; ++c) cj[c] = clampi(g.j0 + c, g.D - 1);
-    double s1[TI][TJ] = {}, s2[TI][TJ] = {};
-    for (int q = 0; q < g.D; ++q) {
-        double x_iq[TI], a_qi[TI], a_qj[TJ], x_qj[TJ];
-#pragma unroll
-        for (int a = 0; a < TI; ++a) { x_iq[a] = X[ri[a] + q]; a_qi[a] = Am[q * g.LD + ci[a]]; }
-#pragma unroll
-        for (int c = 0; c < TJ; ++c) { a_qj[c] = Am[q * g.LD + cj[c]]; x_qj[c] = X[q * g.LD + cj[c]]; }
+        for (int a = 0; a < TI; ++a) {
+            double2* r = reinterpret_cast<double2*>(dst + (g.i0 + a) * G::DT + g.j0);
+            r[0] = make_double2(t[a][0], t[a][1]);
+            r[1] = make_double2(t[a][2], t[a][3]);
+        }
+    } else {
+        if (!g.has_tile) return;
+        const int D = g.D();
 #pragma unroll
         for (int a = 0; a < TI; ++a)
 #pragma unroll
             for (int c = 0; c < TJ; ++c) {
-                s1[a][c] = fma(x_iq[a], a_qj[c], s1[a][c]);
-                s2[a][c] = fma(a_qi[a], x_qj[c], s2[a][c]);
+                const int i = g.i0 + a, j = g.j0 + c;
+                if (i < D && j < D) dst[i * D + j] = t[a][c];
             }
     }
+}
+
+template <class G>
+__device__ inline void store_tile_lds(const G& g, double* dst, const double t[TI][TJ]) {
+    if constexpr (G::DT > 0) {
+#pragma unroll
+        for (int a = 0; a < TI; ++a) {
+            double2* r = reinterpret_cast<double2*>(dst + (g.i0 + a) * g.LD() + g.j0);
+            r[0] = make_double2(t[a][0], t[a][1]);
+            r[1] = make_double2(t[a][2], t[a][3]);
+        }
+    } else {
+        if (!g.has_tile) return;
+        const int D = g.D();
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) {
+                const int i = g.i0 + a, j = g.j0 + c;
+                if (i < D && j < D) dst[i * g.LD() + j] = t[a][c];
+            }
+    }
+}
+
+// acc[a][c] = sum_q Lt[i0+a][q] * Rt[q][j0+c]   ("row x column" product)
+template <class G>
+__device__ inline void prod_rc(const G& g, const double* Lt, const double* Rt, double acc[TI][TJ]) {
 #pragma unroll
     for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int c = 0; c < TJ; ++c) k[a][c] = -G[a][c] + s1[a][c] + s2[a][c];
+        for (int c = 0; c < TJ; ++c) acc[a][c] = 0.0;
+    if (G::DT == 0 && !g.has_tile) return;
+    const int LD = g.LD();
+    if constexpr (G::DT > 0) {
+        const double* l0 = Lt + g.i0 * LD;
+        const double* l1 = l0 + LD;
+        const double* r = Rt + g.j0;
+#pragma unroll 5
+        for (int q = 0; q < G::DT; q += 2) {
+            const double2 a0 = *reinterpret_cast<const double2*>(l0 + q);
+            const double2 a1 = *reinterpret_cast<const double2*>(l1 + q);
+            const double2 x0 = *reinterpret_cast<const double2*>(r + q * LD);
+            const double2 x1 = *reinterpret_cast<const double2*>(r + q * LD + 2);
+            const double2 y0 = *reinterpret_cast<const double2*>(r + (q + 1) * LD);
+            const double2 y1 = *reinterpret_cast<const double2*>(r + (q + 1) * LD + 2);
+            const double xs[TJ] = {x0.x, x0.y, x1.x, x1.y}, ys[TJ] = {y0.x, y0.y, y1.x, y1.y};
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) {
+                acc[0][c] = fma(a0.x, xs[c], acc[0][c]);
+                acc[1][c] = fma(a1.x, xs[c], acc[1][c]);
+            }
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) {
+                acc[0][c] = fma(a0.y, ys[c], acc[0][c]);
+                acc[1][c] = fma(a1.y, ys[c], acc[1][c]);
+            }
+        }
+    } else {
+        const int D = g.D();
+        int ri[TI], cj[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a) ri[a] = clampi(g.i0 + a, D - 1) * LD;
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) cj[c] = clampi(g.j0 + c, D - 1);
+        for (int q = 0; q < D; ++q) {
+            double lv[TI], rv[TJ];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) lv[a] = Lt[ri[a] + q];
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) rv[c] = Rt[q * LD + cj[c]];
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int c = 0; c < TJ; ++c) acc[a][c] = fma(lv[a], rv[c], acc[a][c]);
+        }
+    }
 }
 
-// (Am x)[vi]
-__device__ inline double matvec_row(const NdGeom& g, const double* Am, const double* x) {
-    double acc = 0.0;
-    const double* row = Am + g.vi * g.LD;
-    for (int q = 0; q < g.D; ++q) acc = fma(row[q], x[q], acc);
-    return acc;
+// acc[a][c] = sum_q Lt[i0+a][q] * Rt[j0+c][q]   ("row x row": L R')
+template <class G>
+__device__ inline void prod_rr(const G& g, const double* Lt, const double* Rt, double acc[TI][TJ]) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) acc[a][c] = 0.0;
+    if (!g.has_tile) return;
+    const int LD = g.LD(), D = g.D();
+    int ri[TI], rj[TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a) ri[a] = clampi(g.i0 + a, D - 1) * LD;
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) rj[c] = clampi(g.j0 + c, D - 1) * LD;
+    if constexpr (G::DT > 0) {
+#pragma unroll 5
+        for (int q = 0; q < G::DT; q += 2) {
+            double2 lv[TI], rv[TJ];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) lv[a] = *reinterpret_cast<const double2*>(Lt + ri[a] + q);
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) rv[c] = *reinterpret_cast<const double2*>(Rt + rj[c] + q);
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int c = 0; c < TJ; ++c) acc[a][c] = fma(lv[a].x, rv[c].x, acc[a][c]);
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int c = 0; c < TJ; ++c) acc[a][c] = fma(lv[a].y, rv[c].y, acc[a][c]);
+        }
+    } else {
+        for (int q = 0; q < D; ++q) {
+            double lv[TI], rv[TJ];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) lv[a] = Lt[ri[a] + q];
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) rv[c] = Rt[rj[c] + q];
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int c = 0; c < TJ; ++c) acc[a][c] = fma(lv[a], rv[c], acc[a][c]);
+        }
+    }
+}
+
+// acc[a][c] = sum_q Lt[q][i0+a] * Rt[q][j0+c]   ("column x column": L' R)
+template <class G>
+__device__ inline void prod_cc(const G& g, const double* Lt, const double* Rt, double acc[TI][TJ]) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) acc[a][c] = 0.0;
+    if (!g.has_tile) return;
+    const int LD = g.LD(), D = g.D();
+    int ci[TI], cj[TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a) ci[a] = clampi(g.i0 + a, D - 1);
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) cj[c] = clampi(g.j0 + c, D - 1);
+#pragma unroll 4
+    for (int q = 0; q < D; ++q) {
+        double lv[TI], rv[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a) lv[a] = Lt[q * LD + ci[a]];
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) rv[c] = Rt[q * LD + cj[c]];
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) acc[a][c] = fma(lv[a], rv[c], acc[a][c]);
+    }
+}
+
+// Transposed tile read: t[a][c] = M[j0+c][i0+a]
+template <class G>
+__device__ inline void load_tile_T(const G& g, const double* M, double t[TI][TJ]) {
+    const int D = g.D();
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) {
+            const int i = g.i0 + a, j = g.j0 + c;
+            t[a][c] = (g.has_tile && i < D && j < D) ? M[j * g.LD() + i] : 0.0;
+        }
 }
 
 #define TILE_FOR(a, c) \
     _Pragma("unroll") for (int a = 0; a < TI; ++a) _Pragma("unroll") for (int c = 0; c < TJ; ++c)
 
+// k = Sig - Am*X - X*Am'   (core/fwd_ode.py:45).  Contains a barrier when SYM.
+template <bool SYM, class G>
+__device__ inline void fwd_rhs_tile(const G& g, const double* Am, const double* X, double* Mt,
+                                    const double sig[TI][TJ], double k[TI][TJ]) {
+    double s1[TI][TJ], s2[TI][TJ];
+    prod_rc(g, Am, X, s1);                 // A X
+    if constexpr (SYM) {
+        store_tile_lds(g, Mt, s1);
+        __syncthreads();
+        load_tile_T(g, Mt, s2);            // (A X)' = X A' for symmetric X
+    } else {
+        prod_rr(g, X, Am, s2);             // X A'
+    }
+    TILE_FOR(a, c) k[a][c] = -s1[a][c] - s2[a][c] + sig[a][c];
+}
+
+// k = -G + X*Am + Am'*X   (core/bwd_ode.py:43).  Contains a barrier when SYM.
+template <bool SYM, class G>
+__device__ inline void bwd_rhs_tile(const G& g, const double* Am, const double* X, double* Mt,
+                                    const double Gt[TI][TJ], double k[TI][TJ]) {
+    double s1[TI][TJ], s2[TI][TJ];
+    prod_rc(g, X, Am, s1);                 // X A
+    if constexpr (SYM) {
+        store_tile_lds(g, Mt, s1);
+        __syncthreads();
+        load_tile_T(g, Mt, s2);            // (X A)' = A' X for symmetric X
+    } else {
+        prod_cc(g, Am, X, s2);             // A' X
+    }
+    // (s1 + s2) first: that sum is symmetric in (i, j) bit for bit, which keeps Psi exactly
+    // symmetric whenever G and the jumps are.
+    TILE_FOR(a, c) k[a][c] = -Gt[a][c] + (s1[a][c] + s2[a][c]);
+}
+
+// (Am x)[vi]
+template <class G>
+__device__ inline double matvec_row(const G& g, const double* Am, const double* x) {
+    double acc0 = 0.0, acc1 = 0.0;
+    const double* row = Am + g.vi * g.LD();
+    const int D = g.D();
+    int q = 0;
+#pragma unroll 4
+    for (; q + 1 < D; q += 2) {
+        acc0 = fma(row[q], x[q], acc0);
+        acc1 = fma(row[q + 1], x[q + 1], acc1);
+    }
+    if (q < D) acc0 = fma(row[q], x[q], acc0);
+    return acc0 + acc1;
+}
+
+// LDS carve-up shared by both directions: two A buffers, two X buffers, then the
+// midpoint A (RK2 / RK4 only), the transpose buffer (SYM only) and five vectors.
+// Buffers are addressed as offsets from the one dynamic LDS array: a table of
+// pointers selected at run time would hide the address space from the compiler
+// and turn every LDS access into a flat access.
+template <bool MID, bool SYM>
+struct LdsMap {
+    int MS;
+    __device__ explicit LdsMap(int ms) : MS(ms) {}
+    __device__ __forceinline__ int A(int k) const { return k * MS; }
+    __device__ __forceinline__ int X(int k) const { return (2 + k) * MS; }
+    __device__ __forceinline__ int Amid() const { return 4 * MS; }
+    __device__ __forceinline__ int Mt() const { return (4 + (MID ? 1 : 0)) * MS; }
+    __device__ __forceinline__ int vec() const { return (4 + (MID ? 1 : 0) + (SYM ? 1 : 0)) * MS; }
+};
+
 // ---------------------------------------------------------------------------
 // forward scan, D > 1: one workgroup per problem.
 // core/fwd_ode.py: euler_nD :87, heun_nD :181, rk2_nD :311, rk4_nD :426.
 // ---------------------------------------------------------------------------
-template <int METHOD>
+template <int METHOD, int DT, bool SYM>
 __global__ void __launch_bounds__(512)
-fwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __restrict__ b,
+fwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* __restrict__ b,
                    const double* __restrict__ m0, const double* __restrict__ S0,
                    const double* __restrict__ Sigma, int sigma_stride, double dt,
                    double* __restrict__ m_out, double* __restrict__ S_out) {
     extern __shared__ double lds[];
-    const NdGeom g = make_geom(D);
+    using G = NdGeom<DT>;
+    const G g = make_geom<DT>(Drt);
+    const int D = g.D();
+    constexpr bool MID = (METHOD == VGPA_RK2 || METHOD == VGPA_RK4);
+    const LdsMap<MID, SYM> L(g.MS());
+#define ABUF(k) (lds + L.A(k))
+#define XBUF(k) (lds + L.X(k))
+#define AMID (lds + L.Amid())
+#define MTB (lds + L.Mt())
+#define BBUF(k) (lds + L.vec() + (k) * D)
+#define BMID (lds + L.vec() + 2 * D)
+#define XVEC(k) (lds + L.vec() + (3 + (k)) * D)
+
     const int p = blockIdx.x;
     const size_t DD = (size_t)D * D;
-    double* Abuf[2] = {lds, lds + g.MS};
-    double* Amid = lds + 2 * g.MS;
-    double* Xb[2] = {lds + 3 * g.MS, lds + 4 * g.MS};
-    double* vec = lds + 5 * g.MS;
-    double* bbuf[2] = {vec, vec + D};
-    double* bmid = vec + 2 * D;
-    double* xb[2] = {vec + 3 * D, vec + 4 * D};
-
     const double* Ap = A + (size_t)p * N * DD;
     const double* bp = b + (size_t)p * N * D;
     double* mo = m_out + (size_t)p * N * D;
@@ -214,100 +434,108 @@ fwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __r
     load_tile(g, S0 + (size_t)p * DD, s);
     double mv = (g.vi >= 0) ? m0[(size_t)p * D + g.vi] : 0.0;
 
-    load_matrix_lds(g, Ap, Abuf[0]);
-    store_tile_lds(g, Xb[0], s);
+    load_matrix_lds(g, Ap, ABUF(0));
+    store_tile_lds(g, XBUF(0), s);
     store_tile_global(g, So, s);
     if (g.vi >= 0) {
-        bbuf[0][g.vi] = bp[g.vi];
-        xb[0][g.vi] = mv;
+        BBUF(0)[g.vi] = bp[g.vi];
+        XVEC(0)[g.vi] = mv;
         mo[g.vi] = mv;
     }
-    double pre[PRE];
-    if (N > 1) prefetch_matrix(g, Ap + DD, pre);
+    // Register prefetch, two steps deep: preA holds A[t+1], preB holds A[t+2].
+    double preA[PRE], preB[PRE];
+    const int vsafe = g.vi >= 0 ? g.vi : 0;
+    const int r1 = N > 1 ? 1 : 0, r2 = N > 2 ? 2 : N - 1;
+    prefetch_matrix(g, Ap + (size_t)r1 * DD, preA);
+    prefetch_matrix(g, Ap + (size_t)r2 * DD, preB);
+    double bA = bp[(size_t)r1 * D + vsafe], bB = bp[(size_t)r2 * D + vsafe];
     int cur = 0;   // A buffer holding A[t]
     int xin = 0;   // X buffer holding S[t] / m[t]
 
-    for (int t = 0; t + 1 < N; ++t) {
+    auto step = [&](int t, double (&pre)[PRE], double& bnext) {
         __syncthreads();   // previous step's LDS writes visible, previous reads retired
         const int nxt = cur ^ 1;
-        commit_matrix(g, pre, Abuf[nxt], Abuf[cur], (METHOD == VGPA_RK2 || METHOD == VGPA_RK4) ? Amid : nullptr);
+        commit_matrix(g, pre, ABUF(nxt), ABUF(cur), MID ? AMID : nullptr);
         if (g.vi >= 0) {
-            const double bn = bp[(size_t)(t + 1) * D + g.vi];
-            bbuf[nxt][g.vi] = bn;
-            if (METHOD == VGPA_RK2 || METHOD == VGPA_RK4) bmid[g.vi] = 0.5 * (bbuf[cur][g.vi] + bn);
+            BBUF(nxt)[g.vi] = bnext;
+            if (MID) BMID[g.vi] = 0.5 * (BBUF(cur)[g.vi] + bnext);
         }
-        if (t + 2 < N) prefetch_matrix(g, Ap + (size_t)(t + 2) * DD, pre);
+        {   // rows past the end are clamped: a redundant load instead of a branch
+            const int tp = (t + 3 < N) ? t + 3 : N - 1;
+            prefetch_matrix(g, Ap + (size_t)tp * DD, pre);
+            bnext = bp[(size_t)tp * D + vsafe];
+        }
 
         double k1[TI][TJ], snew[TI][TJ];
         double mnew = 0.0;
-        fwd_rhs_tile(g, Abuf[cur], Xb[xin], sig, k1);
+        fwd_rhs_tile<SYM>(g, ABUF(cur), XBUF(xin), MTB, sig, k1);
         double f1 = 0.0;
-        if (g.vi >= 0) f1 = -matvec_row(g, Abuf[cur], xb[xin]) + bbuf[cur][g.vi];
+        if (g.vi >= 0) f1 = -matvec_row(g, ABUF(cur), XVEC(xin)) + BBUF(cur)[g.vi];
 
         if (METHOD == VGPA_EULER) {
             TILE_FOR(a, c) snew[a][c] = s[a][c] + k1[a][c] * dt;
             mnew = mv + f1 * dt;
-            store_tile_lds(g, Xb[xin ^ 1], snew);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = mnew;
+            store_tile_lds(g, XBUF(xin ^ 1), snew);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = mnew;
             xin ^= 1;
         } else if (METHOD == VGPA_HEUN) {
             double tmp[TI][TJ], k2[TI][TJ];
             TILE_FOR(a, c) tmp[a][c] = s[a][c] + k1[a][c] * dt;
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = mv + f1 * dt;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = mv + f1 * dt;
             __syncthreads();
-            fwd_rhs_tile(g, Abuf[nxt], Xb[xin ^ 1], sig, k2);
+            fwd_rhs_tile<SYM>(g, ABUF(nxt), XBUF(xin ^ 1), MTB, sig, k2);
             TILE_FOR(a, c) snew[a][c] = s[a][c] + h * (k1[a][c] + k2[a][c]);
             if (g.vi >= 0) {
-                const double f2 = -matvec_row(g, Abuf[nxt], xb[xin ^ 1]) + bbuf[nxt][g.vi];
+                const double f2 = -matvec_row(g, ABUF(nxt), XVEC(xin ^ 1)) + BBUF(nxt)[g.vi];
                 mnew = mv + h * (f1 + f2);
             }
-            store_tile_lds(g, Xb[xin], snew);
-            if (g.vi >= 0) xb[xin][g.vi] = mnew;
+            store_tile_lds(g, XBUF(xin), snew);
+            if (g.vi >= 0) XVEC(xin)[g.vi] = mnew;
         } else if (METHOD == VGPA_RK2) {
             double tmp[TI][TJ], k2[TI][TJ];
             TILE_FOR(a, c) tmp[a][c] = s[a][c] + h * k1[a][c];
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = mv + h * f1;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = mv + h * f1;
             __syncthreads();
-            fwd_rhs_tile(g, Amid, Xb[xin ^ 1], sig, k2);
+            fwd_rhs_tile<SYM>(g, AMID, XBUF(xin ^ 1), MTB, sig, k2);
             TILE_FOR(a, c) snew[a][c] = s[a][c] + k2[a][c] * dt;
             if (g.vi >= 0) {
-                const double f2 = -matvec_row(g, Amid, xb[xin ^ 1]) + bmid[g.vi];
+                const double f2 = -matvec_row(g, AMID, XVEC(xin ^ 1)) + BMID[g.vi];
                 mnew = mv + f2 * dt;
             }
-            store_tile_lds(g, Xb[xin], snew);
-            if (g.vi >= 0) xb[xin][g.vi] = mnew;
+            store_tile_lds(g, XBUF(xin), snew);
+            if (g.vi >= 0) XVEC(xin)[g.vi] = mnew;
         } else {   // RK4
             double L1[TI][TJ], L2[TI][TJ], L3[TI][TJ], L4[TI][TJ], tmp[TI][TJ];
             double K1 = f1 * dt, K2 = 0.0, K3 = 0.0, K4 = 0.0;
             TILE_FOR(a, c) { L1[a][c] = k1[a][c] * dt; tmp[a][c] = s[a][c] + 0.5 * L1[a][c]; }
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = mv + 0.5 * K1;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = mv + 0.5 * K1;
             __syncthreads();
-            fwd_rhs_tile(g, Amid, Xb[xin ^ 1], sig, L2);
+            fwd_rhs_tile<SYM>(g, AMID, XBUF(xin ^ 1), MTB, sig, L2);
             TILE_FOR(a, c) { L2[a][c] *= dt; tmp[a][c] = s[a][c] + 0.5 * L2[a][c]; }
-            if (g.vi >= 0) K2 = (-matvec_row(g, Amid, xb[xin ^ 1]) + bmid[g.vi]) * dt;
-            store_tile_lds(g, Xb[xin], tmp);
-            if (g.vi >= 0) xb[xin][g.vi] = mv + 0.5 * K2;
+            if (g.vi >= 0) K2 = (-matvec_row(g, AMID, XVEC(xin ^ 1)) + BMID[g.vi]) * dt;
+            store_tile_lds(g, XBUF(xin), tmp);
+            if (g.vi >= 0) XVEC(xin)[g.vi] = mv + 0.5 * K2;
             __syncthreads();
-            fwd_rhs_tile(g, Amid, Xb[xin], sig, L3);
+            fwd_rhs_tile<SYM>(g, AMID, XBUF(xin), MTB, sig, L3);
             TILE_FOR(a, c) { L3[a][c] *= dt; tmp[a][c] = s[a][c] + L3[a][c]; }
-            if (g.vi >= 0) K3 = (-matvec_row(g, Amid, xb[xin]) + bmid[g.vi]) * dt;
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = mv + K3;
+            if (g.vi >= 0) K3 = (-matvec_row(g, AMID, XVEC(xin)) + BMID[g.vi]) * dt;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = mv + K3;
             __syncthreads();
-            fwd_rhs_tile(g, Abuf[nxt], Xb[xin ^ 1], sig, L4);
+            fwd_rhs_tile<SYM>(g, ABUF(nxt), XBUF(xin ^ 1), MTB, sig, L4);
             TILE_FOR(a, c) {
                 L4[a][c] *= dt;
                 snew[a][c] = s[a][c] + (L1[a][c] + 2.0 * (L2[a][c] + L3[a][c]) + L4[a][c]) / 6.0;
             }
             if (g.vi >= 0) {
-                K4 = (-matvec_row(g, Abuf[nxt], xb[xin ^ 1]) + bbuf[nxt][g.vi]) * dt;
+                K4 = (-matvec_row(g, ABUF(nxt), XVEC(xin ^ 1)) + BBUF(nxt)[g.vi]) * dt;
                 mnew = mv + (K1 + 2.0 * (K2 + K3) + K4) / 6.0;
             }
-            store_tile_lds(g, Xb[xin], snew);
-            if (g.vi >= 0) xb[xin][g.vi] = mnew;
+            store_tile_lds(g, XBUF(xin), snew);
+            if (g.vi >= 0) XVEC(xin)[g.vi] = mnew;
         }
         TILE_FOR(a, c) s[a][c] = snew[a][c];
         store_tile_global(g, So + (size_t)(t + 1) * DD, s);
@@ -316,6 +544,11 @@ fwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __r
             mo[(size_t)(t + 1) * D + g.vi] = mv;
         }
         cur = nxt;
+    };
+
+    for (int t = 0; t + 1 < N; t += 2) {
+        step(t, preA, bA);
+        if (t + 2 < N) step(t + 1, preB, bB);
     }
 }
 
@@ -323,23 +556,22 @@ fwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __r
 // backward scan, D > 1: one workgroup per problem.
 // core/bwd_ode.py: euler_nD :86, heun_nD :177, rk2_nD :305, rk4_nD :427.
 // ---------------------------------------------------------------------------
-template <int METHOD>
+template <int METHOD, int DT, bool SYM>
 __global__ void __launch_bounds__(512)
-bwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __restrict__ dEdm,
+bwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* __restrict__ dEdm,
                    const double* __restrict__ dEdS, const double* __restrict__ jm,
                    const double* __restrict__ jS_dense, const int* __restrict__ obs_flag,
                    const double* __restrict__ jumpS, int jumpS_stride, double dt,
                    double* __restrict__ lam_out, double* __restrict__ Psi_out) {
     extern __shared__ double lds[];
-    const NdGeom g = make_geom(D);
+    using G = NdGeom<DT>;
+    const G g = make_geom<DT>(Drt);
+    const int D = g.D();
+    constexpr bool MID = (METHOD == VGPA_RK2 || METHOD == VGPA_RK4);
+    const LdsMap<MID, SYM> L(g.MS());
+
     const int p = blockIdx.x;
     const size_t DD = (size_t)D * D;
-    double* Abuf[2] = {lds, lds + g.MS};
-    double* Amid = lds + 2 * g.MS;
-    double* Xb[2] = {lds + 3 * g.MS, lds + 4 * g.MS};
-    double* vec = lds + 5 * g.MS;
-    double* xb[2] = {vec, vec + D};
-
     const double* Ap = A + (size_t)p * N * DD;
     const double* gm = dEdm + (size_t)p * N * D;
     const double* gS = dEdS + (size_t)p * N * DD;
@@ -357,32 +589,54 @@ bwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __r
     TILE_FOR(a, c) s[a][c] = 0.0;
     double lv = 0.0;    // lam[t][vi]
     store_tile_global(g, Po + (size_t)(N - 1) * DD, s);
-    store_tile_lds(g, Xb[0], s);
+    store_tile_lds(g, XBUF(0), s);
     if (g.vi >= 0) {
         lo[(size_t)(N - 1) * D + g.vi] = 0.0;
-        xb[0][g.vi] = 0.0;
+        XVEC(0)[g.vi] = 0.0;
     }
-    load_matrix_lds(g, Ap + (size_t)(N - 1) * DD, Abuf[0]);
-    double pre[PRE];
-    if (N > 1) prefetch_matrix(g, Ap + (size_t)(N - 2) * DD, pre);
-    double Gt[TI][TJ], Gp[TI][TJ];
+    load_matrix_lds(g, Ap + (size_t)(N - 1) * DD, ABUF(0));
+    // Register prefetch two steps deep: set A holds row t-1, set B holds row t-2.
+    double preA[PRE], preB[PRE], GA[TI][TJ], GB[TI][TJ];
+    const int vsafe = g.vi >= 0 ? g.vi : 0;
+    const int r1 = N > 1 ? N - 2 : 0, r2 = N > 2 ? N - 3 : 0;
+    prefetch_matrix(g, Ap + (size_t)r1 * DD, preA);
+    load_tile(g, gS + (size_t)r1 * DD, GA);
+    prefetch_matrix(g, Ap + (size_t)r2 * DD, preB);
+    load_tile(g, gS + (size_t)r2 * DD, GB);
+    double gA = gm[(size_t)r1 * D + vsafe], gB = gm[(size_t)r2 * D + vsafe];
+    double Gt[TI][TJ];
     load_tile(g, gS + (size_t)(N - 1) * DD, Gt);
     double gmt = (g.vi >= 0) ? gm[(size_t)(N - 1) * D + g.vi] : 0.0;
     int cur = 0, xin = 0;
 
-    for (int t = N - 1; t >= 1; --t) {
+    auto step = [&](int t, double (&pre)[PRE], double (&Gpre)[TI][TJ], double& gpre) {
         __syncthreads();
         const int prv = cur ^ 1;   // buffer for A[t-1]
-        commit_matrix(g, pre, Abuf[prv], Abuf[cur], (METHOD == VGPA_RK2 || METHOD == VGPA_RK4) ? Amid : nullptr);
-        if (t >= 2) prefetch_matrix(g, Ap + (size_t)(t - 2) * DD, pre);
-        load_tile(g, gS + (size_t)(t - 1) * DD, Gp);
-        const double gmp = (g.vi >= 0) ? gm[(size_t)(t - 1) * D + g.vi] : 0.0;
+        commit_matrix(g, pre, ABUF(prv), ABUF(cur), MID ? AMID : nullptr);
+        double Gp[TI][TJ];
+        TILE_FOR(a, c) Gp[a][c] = Gpre[a][c];
+        const double gmp = gpre;
+        {   // rows before the start are clamped: a redundant load instead of a branch
+            const int tp = (t >= 3) ? t - 3 : 0;
+            prefetch_matrix(g, Ap + (size_t)tp * DD, pre);
+            load_tile(g, gS + (size_t)tp * DD, Gpre);
+            gpre = gm[(size_t)tp * D + vsafe];
+        }
+        // observation jumps at t-1 (core/bwd_ode.py:124,127), fetched early
+        double jd[TI][TJ];
+        if (jSd) {
+            load_tile(g, jSd + (size_t)(t - 1) * DD, jd);
+        } else {
+            const bool on = obs_flag && obs_flag[t - 1];
+            TILE_FOR(a, c) jd[a][c] = on ? jt[a][c] : 0.0;
+        }
+        const double jmv = jmp[(size_t)(t - 1) * D + vsafe];
 
         double k1[TI][TJ], snew[TI][TJ];
         double lnew = 0.0;
-        bwd_rhs_tile(g, Abuf[cur], Xb[xin], Gt, k1);
+        bwd_rhs_tile<SYM>(g, ABUF(cur), XBUF(xin), MTB, Gt, k1);
         double f1 = 0.0;
-        if (g.vi >= 0) f1 = -gmt + matvec_row(g, Abuf[cur], xb[xin]);
+        if (g.vi >= 0) f1 = -gmt + matvec_row(g, ABUF(cur), XVEC(xin));
 
         if (METHOD == VGPA_EULER) {
             TILE_FOR(a, c) snew[a][c] = s[a][c] - k1[a][c] * dt;
@@ -390,26 +644,26 @@ bwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __r
         } else if (METHOD == VGPA_HEUN) {
             double tmp[TI][TJ], k2[TI][TJ];
             TILE_FOR(a, c) tmp[a][c] = s[a][c] - k1[a][c] * dt;
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = lv - f1 * dt;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = lv - f1 * dt;
             __syncthreads();
-            bwd_rhs_tile(g, Abuf[prv], Xb[xin ^ 1], Gp, k2);
+            bwd_rhs_tile<SYM>(g, ABUF(prv), XBUF(xin ^ 1), MTB, Gp, k2);
             TILE_FOR(a, c) snew[a][c] = s[a][c] - h * (k1[a][c] + k2[a][c]);
             if (g.vi >= 0) {
-                const double f2 = -gmp + matvec_row(g, Abuf[prv], xb[xin ^ 1]);
+                const double f2 = -gmp + matvec_row(g, ABUF(prv), XVEC(xin ^ 1));
                 lnew = lv - h * (f1 + f2);
             }
-            xin ^= 1;   // final value goes to the buffer not read in the last stage
+            xin ^= 1;   // now names the buffer read by the last stage
         } else if (METHOD == VGPA_RK2) {
             double tmp[TI][TJ], k2[TI][TJ], Gk[TI][TJ];
             TILE_FOR(a, c) { tmp[a][c] = s[a][c] - h * k1[a][c]; Gk[a][c] = 0.5 * (Gp[a][c] + Gt[a][c]); }
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = lv - h * f1;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = lv - h * f1;
             __syncthreads();
-            bwd_rhs_tile(g, Amid, Xb[xin ^ 1], Gk, k2);
+            bwd_rhs_tile<SYM>(g, AMID, XBUF(xin ^ 1), MTB, Gk, k2);
             TILE_FOR(a, c) snew[a][c] = s[a][c] - k2[a][c] * dt;
             if (g.vi >= 0) {
-                const double f2 = -0.5 * (gmp + gmt) + matvec_row(g, Amid, xb[xin ^ 1]);
+                const double f2 = -0.5 * (gmp + gmt) + matvec_row(g, AMID, XVEC(xin ^ 1));
                 lnew = lv - f2 * dt;
             }
             xin ^= 1;
@@ -422,56 +676,51 @@ bwd_scan_nd_kernel(int N, int D, const double* __restrict__ A, const double* __r
                 tmp[a][c] = s[a][c] - 0.5 * L1[a][c];
                 Gk[a][c] = 0.5 * (Gp[a][c] + Gt[a][c]);
             }
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = lv - 0.5 * K1;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = lv - 0.5 * K1;
             __syncthreads();
-            bwd_rhs_tile(g, Amid, Xb[xin ^ 1], Gk, L2);
+            bwd_rhs_tile<SYM>(g, AMID, XBUF(xin ^ 1), MTB, Gk, L2);
             TILE_FOR(a, c) { L2[a][c] *= dt; tmp[a][c] = s[a][c] - 0.5 * L2[a][c]; }
-            if (g.vi >= 0) K2 = (-gmk + matvec_row(g, Amid, xb[xin ^ 1])) * dt;
-            store_tile_lds(g, Xb[xin], tmp);
-            if (g.vi >= 0) xb[xin][g.vi] = lv - 0.5 * K2;
+            if (g.vi >= 0) K2 = (-gmk + matvec_row(g, AMID, XVEC(xin ^ 1))) * dt;
+            store_tile_lds(g, XBUF(xin), tmp);
+            if (g.vi >= 0) XVEC(xin)[g.vi] = lv - 0.5 * K2;
             __syncthreads();
-            bwd_rhs_tile(g, Amid, Xb[xin], Gk, L3);
+            bwd_rhs_tile<SYM>(g, AMID, XBUF(xin), MTB, Gk, L3);
             TILE_FOR(a, c) { L3[a][c] *= dt; tmp[a][c] = s[a][c] - L3[a][c]; }
-            if (g.vi >= 0) K3 = (-gmk + matvec_row(g, Amid, xb[xin])) * dt;
-            store_tile_lds(g, Xb[xin ^ 1], tmp);
-            if (g.vi >= 0) xb[xin ^ 1][g.vi] = lv - K3;
+            if (g.vi >= 0) K3 = (-gmk + matvec_row(g, AMID, XVEC(xin))) * dt;
+            store_tile_lds(g, XBUF(xin ^ 1), tmp);
+            if (g.vi >= 0) XVEC(xin ^ 1)[g.vi] = lv - K3;
             __syncthreads();
-            bwd_rhs_tile(g, Abuf[prv], Xb[xin ^ 1], Gp, L4);
+            bwd_rhs_tile<SYM>(g, ABUF(prv), XBUF(xin ^ 1), MTB, Gp, L4);
             TILE_FOR(a, c) {
                 L4[a][c] *= dt;
                 snew[a][c] = s[a][c] - (L1[a][c] + 2.0 * (L2[a][c] + L3[a][c]) + L4[a][c]) / 6.0;
             }
             if (g.vi >= 0) {
-                K4 = (-gmp + matvec_row(g, Abuf[prv], xb[xin ^ 1])) * dt;
+                K4 = (-gmp + matvec_row(g, ABUF(prv), XVEC(xin ^ 1))) * dt;
                 lnew = lv - (K1 + 2.0 * (K2 + K3) + K4) / 6.0;
             }
             xin ^= 1;
         }
-        // observation jumps at t-1 (core/bwd_ode.py:124,127)
-        if (jSd) {
-            double jd[TI][TJ];
-            load_tile(g, jSd + (size_t)(t - 1) * DD, jd);
-            TILE_FOR(a, c) snew[a][c] += jd[a][c];
-        } else if (obs_flag && obs_flag[t - 1]) {
-            TILE_FOR(a, c) snew[a][c] += jt[a][c];
-        }
-        if (g.vi >= 0) lnew += jmp[(size_t)(t - 1) * D + g.vi];
-
-        // The last stage read Xb[xin_last]; the new state goes to the other buffer.
-        // For EULER the last (only) stage read Xb[xin]; for the others xin was flipped
-        // above to the buffer read last, so in every case write to xin ^ 1.
+        TILE_FOR(a, c) snew[a][c] += jd[a][c];
+        lnew += jmv;
+        // `xin` names the buffer the last stage read; the new state goes to the other one.
         xin ^= 1;
         TILE_FOR(a, c) { s[a][c] = snew[a][c]; Gt[a][c] = Gp[a][c]; }
-        store_tile_lds(g, Xb[xin], s);
+        store_tile_lds(g, XBUF(xin), s);
         store_tile_global(g, Po + (size_t)(t - 1) * DD, s);
         if (g.vi >= 0) {
             lv = lnew;
             gmt = gmp;
-            xb[xin][g.vi] = lv;
+            XVEC(xin)[g.vi] = lv;
             lo[(size_t)(t - 1) * D + g.vi] = lv;
         }
         cur = prv;
+    };
+
+    for (int t = N - 1; t >= 1; t -= 2) {
+        step(t, preA, GA, gA);
+        if (t - 1 >= 1) step(t - 1, preB, GB, gB);
     }
 }
 
@@ -602,26 +851,67 @@ __global__ void bwd_scan_1d_kernel(int P, int N, const double* __restrict__ A, c
     }
 }
 
-int nd_threads(int D) {
+int nd_threads(int D, bool fixed) {
     const int ntiles = ((D + TI - 1) / TI) * ((D + TJ - 1) / TJ);
+    if (fixed) return ntiles;      // D*D/8 >= D threads, no idle lanes, no predicates
     int n = ntiles > D ? ntiles : D;
     n = vgpa::round_up(n, 64);
     return n < 64 ? 64 : n;
 }
 
-size_t nd_lds_bytes(int D) { return sizeof(double) * ((size_t)5 * D * (D + 1) + 5 * D); }
+// LD = D + 2 for the compile-time sizes, D + 1 otherwise; four to six matrices, five vectors.
+size_t nd_lds_bytes(int D, bool fixed, int method, bool sym) {
+    const size_t LD = fixed ? D + 2 : D + 1;
+    const size_t nmat = 4 + ((method == VGPA_RK2 || method == VGPA_RK4) ? 1 : 0) + (sym ? 1 : 0);
+    return sizeof(double) * (nmat * D * LD + 5 * (size_t)D);
+}
 
-// Dynamic LDS above 64 KiB has to be requested per kernel.
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+template <int METHOD, int DT, bool SYM>
+void launch_fwd(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
+                const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
+    const size_t lds = nd_lds_bytes(D, DT > 0, METHOD, SYM);
+    allow_lds(fwd_scan_nd_kernel<METHOD, DT, SYM>, lds);
+    hipLaunchKernelGGL((fwd_scan_nd_kernel<METHOD, DT, SYM>), dim3(P), dim3(nd_threads(D, DT > 0)), lds, st, N, D, A, b, m0,
+                       S0, Sigma, sigma_stride, dt, m_out, S_out);
+}
+
+template <int METHOD, int DT, bool SYM>
+void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
+                const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
+                double* lam_out, double* Psi_out, hipStream_t st) {
+    const size_t lds = nd_lds_bytes(D, DT > 0, METHOD, SYM);
+    allow_lds(bwd_scan_nd_kernel<METHOD, DT, SYM>, lds);
+    hipLaunchKernelGGL((bwd_scan_nd_kernel<METHOD, DT, SYM>), dim3(P), dim3(nd_threads(D, DT > 0)), lds, st, N, D, A, dEdm,
+                       dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_out, Psi_out);
+}
+
+// Expand (method, D, symmetric) into the template instance.
+#define VGPA_DISPATCH_SCAN(LAUNCH, ...)                                              \
+    do {                                                                             \
+        const bool sym = (flags & VGPA_SCAN_SYMMETRIC) != 0;                         \
+        const int dt_ = D == 40 ? 40 : (D == 16 ? 16 : 0);                           \
+        VGPA_DISPATCH_M(LAUNCH, VGPA_EULER, dt_, sym, __VA_ARGS__);                  \
+        VGPA_DISPATCH_M(LAUNCH, VGPA_HEUN, dt_, sym, __VA_ARGS__);                   \
+        VGPA_DISPATCH_M(LAUNCH, VGPA_RK2, dt_, sym, __VA_ARGS__);                    \
+        VGPA_DISPATCH_M(LAUNCH, VGPA_RK4, dt_, sym, __VA_ARGS__);                    \
+    } while (0)
+#define VGPA_DISPATCH_M(LAUNCH, M, dt_, sym, ...)                                    \
+    if (method == M) {                                                               \
+        if (dt_ == 40) { if (sym) LAUNCH<M, 40, true>(__VA_ARGS__); else LAUNCH<M, 40, false>(__VA_ARGS__); } \
+        else if (dt_ == 16) { if (sym) LAUNCH<M, 16, true>(__VA_ARGS__); else LAUNCH<M, 16, false>(__VA_ARGS__); } \
+        else { if (sym) LAUNCH<M, 0, true>(__VA_ARGS__); else LAUNCH<M, 0, false>(__VA_ARGS__); } \
+    }
+
 }  // namespace
 
 extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, const double* b,
                              const double* m0, const double* S0, const double* Sigma, int sigma_stride,
-                             double dt, double* m_out, double* S_out, void* stream) {
+                             double dt, int flags, double* m_out, double* S_out, void* stream) {
     VGPA_REQUIRE(method >= VGPA_EULER && method <= VGPA_RK4, "vgpa_fwd_scan: Unknown method of integration (%d)", method);
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_fwd_scan: bad sizes P=%d N=%d D=%d", P, N, D);
     if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_fwd_scan: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
@@ -640,23 +930,14 @@ extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, c
         }
 #undef LAUNCH1
     } else {
-        const int bs = nd_threads(D);
-        const size_t lds = nd_lds_bytes(D);
-#define LAUNCHN(M) allow_lds(fwd_scan_nd_kernel<M>, lds); hipLaunchKernelGGL(fwd_scan_nd_kernel<M>, dim3(P), dim3(bs), lds, st, N, D, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
-        switch (method) {
-            case VGPA_EULER: LAUNCHN(VGPA_EULER); break;
-            case VGPA_HEUN: LAUNCHN(VGPA_HEUN); break;
-            case VGPA_RK2: LAUNCHN(VGPA_RK2); break;
-            default: LAUNCHN(VGPA_RK4); break;
-        }
-#undef LAUNCHN
+        VGPA_DISPATCH_SCAN(launch_fwd, P, N, D, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out, st);
     }
     return vgpa::check_launch("vgpa_fwd_scan");
 }
 
 extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, const double* dEsde_dm,
                              const double* dEsde_dS, const double* dEobs_dm, const double* dEobs_dS,
-                             const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
+                             const int* obs_flag, const double* jumpS, int jumpS_stride, double dt, int flags,
                              double* lam_out, double* Psi_out, void* stream) {
     VGPA_REQUIRE(method >= VGPA_EULER && method <= VGPA_RK4, "vgpa_bwd_scan: Unknown method of integration (%d)", method);
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_bwd_scan: bad sizes P=%d N=%d D=%d", P, N, D);
@@ -676,16 +957,8 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
         }
 #undef LAUNCH1
     } else {
-        const int bs = nd_threads(D);
-        const size_t lds = nd_lds_bytes(D);
-#define LAUNCHN(M) allow_lds(bwd_scan_nd_kernel<M>, lds); hipLaunchKernelGGL(bwd_scan_nd_kernel<M>, dim3(P), dim3(bs), lds, st, N, D, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS, jumpS_stride, dt, lam_out, Psi_out)
-        switch (method) {
-            case VGPA_EULER: LAUNCHN(VGPA_EULER); break;
-            case VGPA_HEUN: LAUNCHN(VGPA_HEUN); break;
-            case VGPA_RK2: LAUNCHN(VGPA_RK2); break;
-            default: LAUNCHN(VGPA_RK4); break;
-        }
-#undef LAUNCHN
+        VGPA_DISPATCH_SCAN(launch_bwd, P, N, D, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS,
+                           jumpS_stride, dt, lam_out, Psi_out, st);
     }
     return vgpa::check_launch("vgpa_bwd_scan");
 }

@@ -117,6 +117,8 @@ class Problem:
     Qi: torch.Tensor               # (d,d) inv(chol(R))
     logconst: float                # M (d log 2pi + log det R)
     w: torch.Tensor                # (N,) trapezoid weights
+    sym_fwd: bool = False          # S0 and Sigma are exactly symmetric
+    sym_jump: bool = False         # 0.5 H' Ri H is exactly symmetric (H, Ri diagonal)
     fun: Optional[object] = None   # user energy function evaluated on the host (system < 0)
     sde_struct: Optional[dict] = None
     kl0_cache: Optional[torch.Tensor] = field(default=None, repr=False)
@@ -197,7 +199,19 @@ def make_problem(system, sde, m0, S0, P=1, theta=None, fun=None):
         obs_flag=torch.from_numpy(obs_flag).to(device()),
         obsY=to_dev(obsY), H=to_dev(H), Ri=to_dev(Ri), Qi=to_dev(Qi), logconst=float(logconst),
         w=to_dev(trapz_weights(N, obs_idx)), fun=fun, sde_struct=sde)
+    if D > 1:
+        prob.sym_fwd = bool(np.array_equal(S0a, np.swapaxes(S0a, -1, -2)) and
+                            np.array_equal(Sigma, np.swapaxes(Sigma, -1, -2)))
+        isdiag = lambda M: np.count_nonzero(M - np.diag(np.diagonal(M))) == 0   # noqa: E731
+        prob.sym_jump = bool(H.shape[0] == H.shape[1] and isdiag(H) and isdiag(Ri))
     return prob
+
+
+def esde_output_is_symmetric(system, D):
+    """Whether the energy kernel of this system writes an exactly symmetric
+    dEsde/dS (mirrored in the kernel), so that the backward scan may use its
+    one-product form."""
+    return system == _lib.SYS_L63 or (system == _lib.SYS_L96_UT and D in (16, 40))
 
 
 _LOG2PI = 1.8378770664093453   # core/likelihood.py@10
@@ -210,21 +224,32 @@ def _mat_shape(P, N, D):
     return ((P, N), (P, N)) if D == 1 else ((P, N, D), (P, N, D, D))
 
 
-def fwd_scan(method, A, b, m0, S0, Sigma, dt):
-    """vgpa_fwd_scan.  A (P,N,D,D) / (P,N) -> m, S."""
+def _bitwise_symmetric(t):
+    """True when a (..., D, D) tensor equals its transpose exactly (small tensors
+    only: this synchronises)."""
+    return bool(torch.equal(t, t.transpose(-1, -2)))
+
+
+def fwd_scan(method, A, b, m0, S0, Sigma, dt, symmetric=None):
+    """vgpa_fwd_scan.  A (P,N,D,D) / (P,N) -> m, S.  ``symmetric`` selects the
+    one-product-per-stage kernels; None checks S0 and Sigma for exact symmetry."""
     P, N = A.shape[0], A.shape[1]
     D = 1 if A.dim() == 2 else A.shape[-1]
     vs, ms = _mat_shape(P, N, D)
     m = torch.empty(vs, dtype=F64, device=A.device)
     S = torch.empty(ms, dtype=F64, device=A.device)
     sstride = _par_stride(Sigma, P, D * D)
-    call("vgpa_fwd_scan", method, P, N, D, _p(A), _p(b), _p(m0), _p(S0), _p(Sigma), sstride, float(dt),
+    if symmetric is None:
+        symmetric = D > 1 and _bitwise_symmetric(S0) and _bitwise_symmetric(Sigma)
+    flags = _lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0
+    call("vgpa_fwd_scan", method, P, N, D, _p(A), _p(b), _p(m0), _p(S0), _p(Sigma), sstride, float(dt), flags,
          _p(m), _p(S), _stream())
     return m, S
 
 
-def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, jumpS=None):
-    """vgpa_bwd_scan -> lam, Psi."""
+def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, jumpS=None, symmetric=False):
+    """vgpa_bwd_scan -> lam, Psi.  ``symmetric`` promises exactly symmetric dEdS and
+    jumps (see VGPA_SCAN_SYMMETRIC)."""
     P, N = A.shape[0], A.shape[1]
     D = 1 if A.dim() == 2 else A.shape[-1]
     lam = torch.empty_like(dEdm)
@@ -233,7 +258,8 @@ def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, 
     if jumpS is not None and jumpS.numel() == P * D * D and P > 1:
         jstride = D * D
     call("vgpa_bwd_scan", method, P, N, D, _p(A), _p(dEdm), _p(dEdS), _p(dEobs_dm), _p(dEobs_dS),
-         _p(obs_flag), _p(jumpS), jstride, float(dt), _p(lam), _p(Psi), _stream())
+         _p(obs_flag), _p(jumpS), jstride, float(dt), _lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0,
+         _p(lam), _p(Psi), _stream())
     return lam, Psi
 
 
@@ -378,15 +404,16 @@ class State:
 
 def free_energy(prob, A, b, want_hyper=False):
     """core/varFreeEnergy.py:80-111 for a batch: returns a State with F (P,)."""
-    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt)
+    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
     Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
     if prob.system < 0:
         en = _host_energy(prob, A, b, m, S)
     else:
         en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w,
                           prob.dt, want_hyper)
+    sym = prob.sym_jump and prob.system >= 0 and esde_output_is_symmetric(prob.system, prob.D)
     lam, Psi = bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-                        obs_flag=prob.obs_flag, jumpS=jumpS)
+                        obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym)
     KL0 = kl0(prob)
     F = KL0 + Eobs + en["Esde"]
     return State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"],
