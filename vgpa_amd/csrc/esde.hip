@@ -589,12 +589,18 @@ __global__ void __launch_bounds__(64) esde_l96_ut_kernel(EsdeArgs a) {
 
 #include "esde_l96_tiled.h"
 
+template <int D, bool HYPER>
+void launch_l96_tiled_h(const EsdeArgs& a, size_t total, hipStream_t st) {
+    const size_t lds = sizeof(double) * L96Tiled<D, HYPER>::LDS_DOUBLES;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_ut_tiled_kernel<D, HYPER>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((esde_l96_ut_tiled_kernel<D, HYPER>), dim3((unsigned)total), dim3(256), lds, st, a);
+}
+
 template <int D>
 void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
-    const size_t lds = sizeof(double) * L96Tiled<D>::LDS_DOUBLES;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_ut_tiled_kernel<D>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(esde_l96_ut_tiled_kernel<D>, dim3((unsigned)total), dim3(256), lds, st, a);
+    if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
+    else launch_l96_tiled_h<D, false>(a, total, st);
 }
 
 int launch_esde(int system, const EsdeArgs& a, hipStream_t st) {
@@ -675,3 +681,9 @@ VGPA_DEF_ESDE(vgpa_esde_dw, VGPA_SYS_DW)
 VGPA_DEF_ESDE(vgpa_esde_l63, VGPA_SYS_L63)
 VGPA_DEF_ESDE(vgpa_esde_l63_ut, VGPA_SYS_L63_UT)
 VGPA_DEF_ESDE(vgpa_esde_l96_ut, VGPA_SYS_L96_UT)
+
+#ifdef VGPA_STAMPS
+extern "C" int vgpa_debug_l96_stamps(unsigned long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_l96_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

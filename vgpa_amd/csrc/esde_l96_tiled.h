@@ -1,36 +1,45 @@
 // Lorenz-96 unscented energy kernel, compile-time dimension: one 256-thread
 // workgroup per (problem, time step), all D x D operands in LDS.
 //
-// Phases (block barriers between them):
-//   1  stage A(t), S(t), m, b into LDS (coalesced)
-//   2  <f>, <df/dx>, A m - b
-//   3  blocked Cholesky S = L L' (block width 8): column-block update by all
-//      threads, 8x8 diagonal factor and its inverse in the registers of one
-//      wavefront (cross-lane reads, no LDS), row-panel solve
-//   4  G = A L with 2x4 register tiles, then the +/- sigma-point residuals of the
-//      tile; per-tile partial sums of v+-_i (over d) and of <(f-g)^2>_d (over i)
-//   5  reduce the partial sums; Esde(t)
-//   6  W = L^-1 by block rows (reuses the 8x8 inverses of phase 3)
-//   7  dEsde/dm = (w c / 2) W' (v+ - v-);  V = diag(g) W
-//   8  dEsde/dS = W' V, upper tiles only, mirrored through LDS so the result is
-//      bitwise symmetric, then written with coalesced stores
+// Phases (block barriers between them unless noted):
+//   1  stage A(t), S(t), m into LDS (16-byte coalesced loads)
+//   2  <f>, A m - b, optionally the dense <df/dx>
+//   3  blocked Cholesky S = L L' (block width 8).  Per block column: update by all
+//      threads, barrier, then ONE wavefront factors the 8x8 diagonal block, inverts
+//      the factor and solves the row panel below it (wave-synchronous, cross-lane
+//      register reads, no block barrier inside), barrier.  The pivot recurrence
+//      is the square-root-free one (one reciprocal per pivot on the critical
+//      path); the square roots are taken off the chain.
+//   4  G = A L with 2x4 register tiles and 16-byte LDS reads, then the +/-
+//      sigma-point residuals of the tile; partial sums of v+-_i over d are
+//      combined between lane pairs, then stored per tile pair
+//   5  wavefront 0 reduces the partial sums -> Esde(t), u = v+ - v-, g;
+//      CONCURRENTLY wavefronts 1..3 compute W = L^-1 by block columns
+//      (wave-synchronous chains, no block barrier)
+//   6  dEsde/dm = (w c / 2) W' u;  V = diag(g) W
+//   7  dEsde/dS = W' V on the upper tiles, written to (i,j) and (j,i): the result
+//      is bitwise symmetric
+//
+// HYPER adds the per-component <(f-g)^2> integrand (dSig_t), which costs one more
+// LDS array and one resident workgroup per CU; the free-energy path runs without.
 //
 // Included by esde.hip inside its anonymous namespace.
 
-template <int D>
+template <int D, bool HYPER>
 struct L96Tiled {
-    static constexpr int LD = D + 1;          // padded leading dimension
+    static constexpr int LD = D + 2;          // even: rows stay 16-byte aligned
     static constexpr int MS = D * LD;
     static constexpr int NB = 8;              // Cholesky block width
     static constexpr int NBLK = D / NB;
     static constexpr int TI = 2, TJ = 4;      // register tile
     static constexpr int NTI = D / TI, NTJ = D / TJ;
+    static constexpr int NPAIR = NTI / 2;
     static constexpr int NT = 256;
-    static_assert(D % NB == 0 && D % TJ == 0 && D % TI == 0, "D must be a multiple of 8");
+    static_assert(D % NB == 0, "D must be a multiple of 8");
     static_assert(NTI * NTJ <= NT, "one register tile per thread");
-    static_assert(2 * NTI * D <= MS, "partial sums must fit the scratch matrix");
-    // LDS doubles: Lm, Am, Xb matrices; mean-square partials; 8x8 inverses; vectors
-    static constexpr int LDS_DOUBLES = 3 * MS + NTJ * D + NBLK * NB * NB + 8 * D + 8;
+    static constexpr int XB = 2 * NPAIR * D + (HYPER ? NTJ * D : 0);
+    // Lm, Am | partial sums | 8x8 inverses | per-wave 8x8 scratch | vectors | scalars
+    static constexpr int LDS_DOUBLES = 2 * MS + XB + NBLK * NB * NB + 4 * NB * NB + 6 * D + 8;
 };
 
 __device__ inline double readlane_f64(double v, int lane) {
@@ -39,7 +48,7 @@ __device__ inline double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(p): hardware estimate refined by two Newton steps (full double precision).
+// 1/sqrt(p) and 1/p: hardware estimate plus Newton refinement.
 __device__ inline double rsqrt_refined(double p) {
     double r = __builtin_amdgcn_rsq(p);
     double e = fma(-(p * r), r, 1.0);
@@ -48,68 +57,101 @@ __device__ inline double rsqrt_refined(double p) {
     r = fma(0.5 * r, e, r);
     return r;
 }
+__device__ inline double rcp_refined(double p) {
+    double q = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, q, 1.0);
+    q = fma(q, e, q);
+    e = fma(-p, q, 1.0);
+    q = fma(q, e, q);
+    return q;
+}
 
-template <int D>
+// Orders LDS traffic between the lanes of one wavefront (no instruction is
+// emitted; it only stops the compiler from moving LDS accesses across it).
+__device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+#ifdef VGPA_STAMPS
+// Diagnostic build only: per-phase cycle counts of one workgroup, lane 0.
+__device__ unsigned long long g_l96_stamps[32];
+#define VGPA_STAMP(k) do { if (blockIdx.x == 1000 && threadIdx.x == 0) g_l96_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VGPA_STAMP(k) do { } while (0)
+#endif
+
+template <int D, bool HYPER>
 __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
-    using C = L96Tiled<D>;
+    using C = L96Tiled<D, HYPER>;
     constexpr int LD = C::LD, MS = C::MS, NB = C::NB, NBLK = C::NBLK, NT = C::NT;
-    constexpr int TI = C::TI, TJ = C::TJ, NTI = C::NTI, NTJ = C::NTJ;
-    extern __shared__ double lds[];
-    double* Lm = lds;                 // S -> L -> V = diag(g) W
-    double* Am = lds + MS;            // A -> W = L^-1
-    double* Xb = lds + 2 * MS;        // partial sums of v+-, later the symmetric output
-    double* Mb = lds + 3 * MS;        // [NTJ][D] partial sums of w (r+^2 + r-^2)
-    double* Tb = Mb + NTJ * D;        // [NBLK][8][8] inverses of the diagonal blocks of L
-    double* mv = Tb + NBLK * NB * NB;
-    double* bv = mv + D;
-    double* basev = bv + D;           // A m - b
-    double* sIv = basev + D;
-    double* uv = sIv + D;             // v+ - v-
-    double* gv = uv + D;              // (v+ + v-)/8 - Esde/2
-    double* sc = gv + D;              // [0] = pivot failure flag, [1] = Esde
-    const int tid = threadIdx.x;
-    const size_t e = blockIdx.x;      // p * N + t
-    const int p = (int)(e / a.N);
+    constexpr int TI = C::TI, TJ = C::TJ, NTI = C::NTI, NTJ = C::NTJ, NPAIR = C::NPAIR;
     constexpr int DD = D * D;
+    extern __shared__ double lds[];
+    double* Lm = lds;                         // S -> L -> V = diag(g) W
+    double* Am = lds + MS;                    // A -> W = L^-1
+    double* Vp = lds + 2 * MS;                // [NPAIR][D] partial sums of v+
+    double* Vm = Vp + NPAIR * D;              // [NPAIR][D] partial sums of v-
+    double* Mb = Vm + NPAIR * D;              // [NTJ][D] partial sums of w (r+^2 + r-^2)  (HYPER)
+    double* Tb = lds + 2 * MS + C::XB;        // [NBLK][8][8] inverses of the diagonal blocks of L
+    double* Pw = Tb + NBLK * NB * NB;         // [4][8][8] per-wavefront scratch
+    double* mv = Pw + 4 * NB * NB;
+    double* basev = mv + D;                   // A m - b
+    double* sIv = basev + D;
+    double* uv = sIv + D;                     // v+ - v-
+    double* gv = uv + D;                      // (v+ + v-)/8 - Esde/2
+    double* a0v = gv + D;                     // squared centre-point residuals
+    double* sc = a0v + D;                     // [0] = pivot failure flag
+    const int tid = threadIdx.x;
+    const int wid = tid >> 6, lane = tid & 63;
+    const size_t e = blockIdx.x;              // p * N + t
+    const int p = (int)(e / a.N);
     const double theta = a.theta[(size_t)p * a.theta_stride];
 
+    VGPA_STAMP(0);
     // ---- phase 1 ----------------------------------------------------------
     {
-        const double* Ag = a.A + e * DD;
-        const double* Sg = a.S + e * DD;
+        const double2* Ag = reinterpret_cast<const double2*>(a.A + e * DD);
+        const double2* Sg = reinterpret_cast<const double2*>(a.S + e * DD);
 #pragma unroll
-        for (int q0 = 0; q0 < DD; q0 += NT) {
+        for (int q0 = 0; q0 < DD / 2; q0 += NT) {
             const int q = q0 + tid;
-            if (q < DD) {
-                const int o = (q / D) * LD + (q % D);
-                Am[o] = Ag[q];
-                Lm[o] = Sg[q];
+            if (q < DD / 2) {
+                const int o = ((2 * q) / D) * LD + ((2 * q) % D);
+                *reinterpret_cast<double2*>(Am + o) = Ag[q];
+                *reinterpret_cast<double2*>(Lm + o) = Sg[q];
             }
         }
         if (tid < D) {
             mv[tid] = a.m[e * D + tid];
-            bv[tid] = a.b[e * D + tid];
             sIv[tid] = a.sig_inv_diag[(size_t)p * a.sig_stride + tid];
         }
         if (tid == 0) sc[0] = 0.0;
     }
     __syncthreads();
 
+    VGPA_STAMP(1);
     // ---- phase 2 ----------------------------------------------------------
     if (tid < D) {
         const int l = tid;
         const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
-        double am = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < D; ++k) am = fma(Am[l * LD + k], mv[k], am);
-        const double base = am - bv[l];
+        double am0 = 0.0, am1 = 0.0;
+#pragma unroll 5
+        for (int k = 0; k < D; k += 2) {
+            const double2 av = *reinterpret_cast<const double2*>(Am + l * LD + k);
+            am0 = fma(av.x, mv[k], am0);
+            am1 = fma(av.y, mv[k + 1], am1);
+        }
+        const double base = (am0 + am1) - a.b[e * D + l];
         basev[l] = base;
         const double Cxx = Lm[f1 * LD + b1] - Lm[b2 * LD + b1];
-        const double Ef = Cxx + (mv[f1] - mv[b2]) * mv[b1] - mv[l] + theta;
+        const double f0 = (mv[f1] - mv[b2]) * mv[b1] - mv[l] + theta;   // drift at the mean
+        const double Ef = Cxx + f0;
         a.Ef[e * D + l] = Ef;
         if (a.dth_t) a.dth_t[e * D + l] = Ef + base;
+        const double r0 = f0 + base;
+        a0v[l] = r0 * r0;
     }
     if (a.Edf) {
+        // Jacobian of the drift at the mean; row i is filled in the order
+        // [i] = -1, [i+1] = m[i-1], [i-2] = -m[i-1], [i-1] = m[i+1] - m[i-2].
         double* E = a.Edf + e * DD;
 #pragma unroll
         for (int q0 = 0; q0 < DD; q0 += NT) {
@@ -128,6 +170,7 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
     }
     __syncthreads();
 
+    VGPA_STAMP(2);
     // ---- phase 3: blocked Cholesky ------------------------------------------
 #pragma unroll 1
     for (int J = 0; J < NBLK; ++J) {
@@ -141,34 +184,43 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll 4
                 for (int k = 0; k < c0; k += 2) {
-                    s0 = fma(ri[k], rc[k], s0);
-                    s1 = fma(ri[k + 1], rc[k + 1], s1);
+                    const double2 x = *reinterpret_cast<const double2*>(ri + k);
+                    const double2 y = *reinterpret_cast<const double2*>(rc + k);
+                    s0 = fma(x.x, y.x, s0);
+                    s1 = fma(x.y, y.y, s1);
                 }
                 Lm[i * LD + c0 + c] -= (s0 + s1);
             }
             __syncthreads();
         }
-        // (b) factor the 8x8 diagonal block and invert its factor: wavefront 0,
-        //     lane j < 8 holds column j; U = L' is built row by row.
-        if (tid < 64) {
-            const int j = tid & 7;
-            double s[NB], rinv[NB];
+        // (b) wavefront 0: factor the 8x8 diagonal block, invert its factor, solve the
+        //     rows below.  Lane j (mod 8) holds column j of the symmetric block, read
+        //     from the lower triangle; U = L' is built row by row.
+        if (wid == 0) {
+            const int j = lane & 7;
+            double s[NB], piv[NB];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) s[i] = Lm[(c0 + j) * LD + c0 + i];   // lower triangle, as LAPACK reads it
+            for (int i = 0; i < NB; ++i) s[i] = Lm[(c0 + j) * LD + c0 + i];
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const double pk = readlane_f64(s[k], k);
-                ok = ok && (pk > 0.0);
-                rinv[k] = rsqrt_refined(pk);
-                s[k] *= rinv[k];
+                piv[k] = readlane_f64(s[k], k);
+                ok = ok && (piv[k] > 0.0);
+                const double qk = rcp_refined(piv[k]);
 #pragma unroll
                 for (int i = k + 1; i < NB; ++i) {
-                    const double uki = readlane_f64(s[k], i);
-                    s[i] = fma(-uki, s[k], s[i]);
+                    const double mi = readlane_f64(s[k], i) * qk;
+                    s[i] = fma(-mi, s[k], s[i]);
                 }
             }
-            // Y = U^-1 (upper), column j in this lane; T = Y' = inverse of the lower factor.
+            double rinv[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                rinv[k] = rsqrt_refined(piv[k]);
+                s[k] *= rinv[k];                       // U[k][j]
+            }
+            // Y = U^-1 (upper), column j in this lane; T = Y' inverts the lower factor.
+            // Terms are accumulated oldest-first so each row waits on one new value only.
             double y[NB];
 #pragma unroll
             for (int i = 0; i < NB; ++i) y[i] = 0.0;
@@ -176,45 +228,44 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
             for (int i = NB - 1; i >= 0; --i) {
                 double acc = 0.0;
 #pragma unroll
-                for (int k = i + 1; k < NB; ++k) acc = fma(readlane_f64(s[i], k), y[k], acc);
+                for (int k = NB - 1; k > i; --k) acc = fma(readlane_f64(s[i], k), y[k], acc);
                 y[i] = (j == i) ? rinv[i] : -rinv[i] * acc;
             }
-            if (tid < NB) {
+            if (lane < NB) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
-                    if (i <= j) Lm[(c0 + j) * LD + c0 + i] = s[i];     // L[j][i] = U[i][j]
-                    Tb[J * NB * NB + j * NB + i] = (i <= j) ? y[i] : 0.0;   // T[j][i] = Y[i][j]
+                    if (i <= j) Lm[(c0 + j) * LD + c0 + i] = s[i];          // L[j][i] = U[i][j]
+                    Tb[J * NB * NB + j * NB + i] = (i <= j) ? y[i] : 0.0;     // T[j][i] = Y[i][j]
                 }
-                if (!ok && tid == 0) sc[0] = 1.0;
+                if (!ok && lane == 0) sc[0] = 1.0;
+            }
+            wave_lds_fence();
+            // row panel: L[i][c0..c0+7] = S'[i][c0..c0+7] T'   for rows i >= c0 + 8
+            const double* T = Tb + J * NB * NB;
+            const int c = lane & 7;
+            double tr[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) tr[k] = T[c * NB + k];               // zero for k > c
+#pragma unroll 1
+            for (int i0 = c0 + NB; i0 < D; i0 += NB) {
+                const int i = i0 + (lane >> 3);
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NB; k += 2) {
+                    const double2 x = *reinterpret_cast<const double2*>(Lm + i * LD + c0 + k);
+                    acc = fma(x.x, tr[k], acc);
+                    acc = fma(x.y, tr[k + 1], acc);
+                }
+                wave_lds_fence();        // every lane has read the row before it is overwritten
+                Lm[i * LD + c0 + c] = acc;
             }
         }
         __syncthreads();
         if (sc[0] != 0.0) break;   // uniform: every thread reads the same flag
-        // (c) rows below the block: L[i][c0..c0+7] = S'[i][c0..c0+7] T'
-        {
-            const int i = c0 + NB + tid;
-            if (i < D) {
-                double r[NB], o[NB];
-#pragma unroll
-                for (int k = 0; k < NB; ++k) r[k] = Lm[i * LD + c0 + k];
-                const double* T = Tb + J * NB * NB;
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int k = 0; k <= c; ++k) acc = fma(r[k], T[c * NB + k], acc);
-                    o[c] = acc;
-                }
-#pragma unroll
-                for (int c = 0; c < NB; ++c) Lm[i * LD + c0 + c] = o[c];
-            }
-        }
-        __syncthreads();
     }
     if (sc[0] != 0.0) {
         // Not positive definite.  The reference falls back to diagonal sigma points,
-        // which needs a general inverse of S: left to the generic path's status
-        // handling -- flag the step and poison its energy outputs.
+        // which needs a general inverse of S: flag the step and poison its outputs.
         const double nan = __builtin_nan("");
         if (tid == 0) {
             a.Esde_t[e] = nan;
@@ -227,6 +278,7 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
         for (int q = tid; q < DD; q += NT) a.dEdS[e * DD + q] = nan;
         return;
     }
+    VGPA_STAMP(3);
     // strict upper triangle of L := 0 (column reads below need no masking)
 #pragma unroll
     for (int q0 = 0; q0 < DD; q0 += NT) {
@@ -243,24 +295,32 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
     const double cs = sqrt(c2);
     const double w0 = kappa / c2, w1 = 1.0 / (2.0 * c2);
 
+    VGPA_STAMP(4);
     // ---- phase 4: G = A L and the sigma-point residuals ----------------------
-    double* Vp = Xb;                  // [NTI][D]
-    double* Vm = Xb + NTI * D;        // [NTI][D]
     if (tid < NTI * NTJ) {
-        const int di = tid / NTJ, ij = tid % NTJ;
+        const int ij = tid / NTI, di = tid % NTI;      // lanes 2k, 2k+1 share ij, adjacent di
         const int d0 = di * TI, i0 = ij * TJ;
         double G[TI][TJ] = {};
         const double* A0 = Am + d0 * LD;
         const double* A1 = A0 + LD;
-#pragma unroll 4
-        for (int j = i0; j < D; ++j) {
-            const double a0 = A0[j], a1 = A1[j];
-            const double* Lr = Lm + j * LD + i0;
+#pragma unroll 2
+        for (int j = i0; j < D; j += 2) {
+            const double2 a0 = *reinterpret_cast<const double2*>(A0 + j);
+            const double2 a1 = *reinterpret_cast<const double2*>(A1 + j);
+            const double2 x0 = *reinterpret_cast<const double2*>(Lm + j * LD + i0);
+            const double2 x1 = *reinterpret_cast<const double2*>(Lm + j * LD + i0 + 2);
+            const double2 y0 = *reinterpret_cast<const double2*>(Lm + (j + 1) * LD + i0);
+            const double2 y1 = *reinterpret_cast<const double2*>(Lm + (j + 1) * LD + i0 + 2);
+            const double xs[TJ] = {x0.x, x0.y, x1.x, x1.y}, ys[TJ] = {y0.x, y0.y, y1.x, y1.y};
 #pragma unroll
             for (int c = 0; c < TJ; ++c) {
-                const double lv = Lr[c];
-                G[0][c] = fma(a0, lv, G[0][c]);
-                G[1][c] = fma(a1, lv, G[1][c]);
+                G[0][c] = fma(a0.x, xs[c], G[0][c]);
+                G[1][c] = fma(a1.x, xs[c], G[1][c]);
+            }
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) {
+                G[0][c] = fma(a0.y, ys[c], G[0][c]);
+                G[1][c] = fma(a1.y, ys[c], G[1][c]);
             }
         }
         // rows d0-2 .. d0+2 (cyclic) of columns i0..i0+3 of c L, and the matching means
@@ -271,112 +331,126 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
             rr[q] = (d0 + D - 2 + q) % D;
             mm[q] = mv[rr[q]];
         }
+        double o[5][TJ];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const double2 v0 = *reinterpret_cast<const double2*>(Lm + rr[q] * LD + i0);
+            const double2 v1 = *reinterpret_cast<const double2*>(Lm + rr[q] * LD + i0 + 2);
+            o[q][0] = cs * v0.x; o[q][1] = cs * v0.y; o[q][2] = cs * v1.x; o[q][3] = cs * v1.y;
+        }
+        const double bs[TI] = {basev[d0], basev[d0 + 1]};
+        const double si[TI] = {sIv[d0], sIv[d0 + 1]};
         double mb[TI] = {0.0, 0.0};
+        double vpc[TJ], vmc[TJ];
 #pragma unroll
         for (int c = 0; c < TJ; ++c) {
-            double o[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) o[q] = cs * Lm[rr[q] * LD + i0 + c];
-            double vpc = 0.0, vmc = 0.0;
+            vpc[c] = 0.0;
+            vmc[c] = 0.0;
 #pragma unroll
             for (int r = 0; r < TI; ++r) {
-                // state index d = d0 + r sits at position q = r + 2 of the window
-                const double xm2p = mm[r] + o[r], xm1p = mm[r + 1] + o[r + 1];
-                const double x0p = mm[r + 2] + o[r + 2], xp1p = mm[r + 3] + o[r + 3];
-                const double xm2m = mm[r] - o[r], xm1m = mm[r + 1] - o[r + 1];
-                const double x0m = mm[r + 2] - o[r + 2], xp1m = mm[r + 3] - o[r + 3];
+                // state index d = d0 + r sits at position r + 2 of the 5-row window
+                const double xm2p = mm[r] + o[r][c], xm1p = mm[r + 1] + o[r + 1][c];
+                const double x0p = mm[r + 2] + o[r + 2][c], xp1p = mm[r + 3] + o[r + 3][c];
+                const double xm2m = mm[r] - o[r][c], xm1m = mm[r + 1] - o[r + 1][c];
+                const double x0m = mm[r + 2] - o[r + 2][c], xp1m = mm[r + 3] - o[r + 3][c];
                 const double fp = (xp1p - xm2p) * xm1p - x0p + theta;
                 const double fm = (xp1m - xm2m) * xm1m - x0m + theta;
-                const double bs = basev[d0 + r];
                 const double cG = cs * G[r][c];
-                const double rp = fp + bs + cG, rm = fm + bs - cG;
+                const double rp = fp + bs[r] + cG, rm = fm + bs[r] - cG;
                 const double rp2 = rp * rp, rm2 = rm * rm;
-                const double si = sIv[d0 + r];
-                vpc = fma(si, rp2, vpc);
-                vmc = fma(si, rm2, vmc);
-                mb[r] += w1 * (rp2 + rm2);
+                vpc[c] = fma(si[r], rp2, vpc[c]);
+                vmc[c] = fma(si[r], rm2, vmc[c]);
+                if (HYPER) mb[r] += w1 * (rp2 + rm2);
             }
-            Vp[di * D + i0 + c] = vpc;
-            Vm[di * D + i0 + c] = vmc;
         }
+        // combine the two d-tiles of a lane pair, even lane stores
 #pragma unroll
-        for (int r = 0; r < TI; ++r) Mb[ij * D + d0 + r] = mb[r];
+        for (int c = 0; c < TJ; ++c) {
+            vpc[c] += __shfl_xor(vpc[c], 1, 64);
+            vmc[c] += __shfl_xor(vmc[c], 1, 64);
+        }
+        if ((di & 1) == 0) {
+            double* vp = Vp + (di >> 1) * D + i0;
+            double* vm = Vm + (di >> 1) * D + i0;
+            *reinterpret_cast<double2*>(vp) = make_double2(vpc[0], vpc[1]);
+            *reinterpret_cast<double2*>(vp + 2) = make_double2(vpc[2], vpc[3]);
+            *reinterpret_cast<double2*>(vm) = make_double2(vmc[0], vmc[1]);
+            *reinterpret_cast<double2*>(vm + 2) = make_double2(vmc[2], vmc[3]);
+        }
+        if (HYPER) {
+#pragma unroll
+            for (int r = 0; r < TI; ++r) Mb[ij * D + d0 + r] = mb[r];
+        }
     }
     __syncthreads();
 
-    // ---- phase 5: reductions (wavefront 0) -----------------------------------
-    if (tid < 64) {
-        const int l = tid;
-        double vpl = 0.0, vml = 0.0, a0 = 0.0, mbar = 0.0;
+    VGPA_STAMP(5);
+    // ---- phase 5: wavefront 0 reduces, wavefronts 1..3 invert L ----------------
+    double* Wm = Am;
+    if (wid == 0) {
+        const int l = lane;
+        double vpl = 0.0, vml = 0.0, a0 = 0.0;
         if (l < D) {
 #pragma unroll
-            for (int q = 0; q < NTI; ++q) {
+            for (int q = 0; q < NPAIR; ++q) {
                 vpl += Vp[q * D + l];
                 vml += Vm[q * D + l];
             }
-            const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
-            const double f0 = (mv[f1] - mv[b2]) * mv[b1] - mv[l] + theta;
-            const double r0 = f0 + basev[l];
-            a0 = sIv[l] * r0 * r0;
-            mbar = w0 * r0 * r0;
-#pragma unroll
-            for (int q = 0; q < NTJ; ++q) mbar += Mb[q * D + l];
+            a0 = sIv[l] * a0v[l];
         }
         const double v0 = wave_sum(a0);
         const double Esde = 0.5 * (w0 * v0 + w1 * wave_sum(vpl + vml));
         if (l < D) {
             uv[l] = vpl - vml;
             gv[l] = 0.125 * (vpl + vml) - 0.5 * Esde;
-            if (a.dSig_t) a.dSig_t[e * D + l] = mbar;
+            if (HYPER && a.dSig_t) {
+                double mbar = w0 * a0v[l];
+#pragma unroll
+                for (int q = 0; q < NTJ; ++q) mbar += Mb[q * D + l];
+                a.dSig_t[e * D + l] = mbar;
+            }
         }
         if (l == 0) {
             a.Esde_t[e] = Esde;
             if (a.status) a.status[e] = 0;
         }
-    }
-    // ---- phase 6: W = L^-1 into Am, by block rows ----------------------------
-    double* Wm = Am;
-    __syncthreads();
-#pragma unroll
-    for (int q0 = 0; q0 < DD; q0 += NT) {   // zero, then the diagonal blocks
-        const int q = q0 + tid;
-        if (q < DD) Wm[(q / D) * LD + (q % D)] = 0.0;
-    }
-    __syncthreads();
-    for (int q = tid; q < NBLK * NB * NB; q += NT) {
-        const int J = q / (NB * NB), r = (q / NB) % NB, c = q % NB;
-        Wm[(J * NB + r) * LD + J * NB + c] = Tb[q];
-    }
-    __syncthreads();
-    double* Pb = Xb;                  // [NB][D] products sum_K L_IK W_KJ
-#pragma unroll 1
-    for (int I = 1; I < NBLK; ++I) {
-        const int r0 = I * NB;
-        const int r = tid / r0, c = tid % r0;      // r < 8 rows, c < r0 columns
-        if (tid < NB * r0) {
-            const double* Lr = Lm + (r0 + r) * LD;
-            double s0 = 0.0, s1 = 0.0;
-            // k runs over the columns of L left of the diagonal block; W[k][c] = 0 for k < c
-            const int kb = (c / NB) * NB;
+    } else {
+        // W = L^-1, one block column per pass: W_JJ = T_J,
+        // W_IJ = -T_I sum_{K=J}^{I-1} L_IK W_KJ.  Lane (r, c) owns entry (r, c) of the
+        // current 8x8 block; the chain over I is wave-synchronous.
+        const int r = lane >> 3, c = lane & 7;
+        double* Pq = Pw + wid * NB * NB;
+        for (int J = wid - 1; J < NBLK; J += 3) {
+            const int c0 = J * NB;
+            for (int i = lane; i < c0 * NB; i += 64) Wm[(i / NB) * LD + c0 + (i % NB)] = 0.0;   // blocks above
+            Wm[(c0 + r) * LD + c0 + c] = Tb[J * NB * NB + r * NB + c];
+            wave_lds_fence();
+            for (int I = J + 1; I < NBLK; ++I) {
+                const int r0 = I * NB;
+                const double* Lr = Lm + (r0 + r) * LD;
+                double s0 = 0.0, s1 = 0.0;
 #pragma unroll 4
-            for (int k = kb; k < r0; k += 2) {
-                s0 = fma(Lr[k], Wm[k * LD + c], s0);
-                s1 = fma(Lr[k + 1], Wm[(k + 1) * LD + c], s1);
-            }
-            Pb[r * D + c] = s0 + s1;
-        }
-        __syncthreads();
-        if (tid < NB * r0) {
-            const double* T = Tb + I * NB * NB + r * NB;
-            double acc = 0.0;
+                for (int k = c0; k < r0; k += 2) {
+                    const double2 lv = *reinterpret_cast<const double2*>(Lr + k);
+                    s0 = fma(lv.x, Wm[k * LD + c0 + c], s0);
+                    s1 = fma(lv.y, Wm[(k + 1) * LD + c0 + c], s1);
+                }
+                Pq[r * NB + c] = s0 + s1;
+                wave_lds_fence();
+                const double* T = Tb + I * NB * NB + r * NB;
+                double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) acc = fma(T[k], Pb[k * D + c], acc);
-            Wm[(r0 + r) * LD + c] = -acc;
+                for (int k = 0; k < NB; ++k) acc = fma(T[k], Pq[k * NB + c], acc);
+                wave_lds_fence();
+                Wm[(r0 + r) * LD + c0 + c] = -acc;
+                wave_lds_fence();
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
 
-    // ---- phase 7 ---------------------------------------------------------------
+    VGPA_STAMP(6);
+    // ---- phase 6 ---------------------------------------------------------------
     if (tid < D) {
         const int l = tid;
         double y0 = 0.0, y1 = 0.0;
@@ -388,17 +462,19 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
         a.dEdm[e * D + l] = 0.5 * w1 * cs * (y0 + y1);
     }
 #pragma unroll
-    for (int q0 = 0; q0 < DD; q0 += NT) {
+    for (int q0 = 0; q0 < DD / 2; q0 += NT) {
         const int q = q0 + tid;
-        if (q < DD) {
-            const int k = q / D, o = k * LD + (q % D);
-            Lm[o] = gv[k] * Wm[o];
+        if (q < DD / 2) {
+            const int k = (2 * q) / D, o = k * LD + ((2 * q) % D);
+            const double gk = gv[k];
+            const double2 w = *reinterpret_cast<const double2*>(Wm + o);
+            *reinterpret_cast<double2*>(Lm + o) = make_double2(gk * w.x, gk * w.y);
         }
     }
     __syncthreads();
 
-    // ---- phase 8: dEsde/dS = W' V, upper tiles, mirrored ----------------------
-    double* Ob = Xb;
+    VGPA_STAMP(7);
+    // ---- phase 7: dEsde/dS = W' V, upper tiles, mirrored -----------------------
     if (tid < NTI * NTJ) {
         const int ti = tid / NTJ, tj = tid % NTJ;
         const int i0 = ti * TI, j0 = tj * TJ;
@@ -407,34 +483,41 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
             const int k0 = (i0 > j0) ? i0 : j0;
 #pragma unroll 4
             for (int k = k0; k < D; ++k) {
-                const double w0k = Wm[k * LD + i0], w1k = Wm[k * LD + i0 + 1];
-                const double* Vr = Lm + k * LD + j0;
+                const double2 wv = *reinterpret_cast<const double2*>(Wm + k * LD + i0);
+                const double2 v0 = *reinterpret_cast<const double2*>(Lm + k * LD + j0);
+                const double2 v1 = *reinterpret_cast<const double2*>(Lm + k * LD + j0 + 2);
+                const double vs[TJ] = {v0.x, v0.y, v1.x, v1.y};
 #pragma unroll
                 for (int c = 0; c < TJ; ++c) {
-                    const double vv = Vr[c];
-                    acc[0][c] = fma(w0k, vv, acc[0][c]);
-                    acc[1][c] = fma(w1k, vv, acc[1][c]);
+                    acc[0][c] = fma(wv.x, vs[c], acc[0][c]);
+                    acc[1][c] = fma(wv.y, vs[c], acc[1][c]);
                 }
             }
+            double* Gd = a.dEdS + e * DD;
+            if (i0 + TI - 1 <= j0) {
+                // tile strictly above the diagonal: full rows, and its mirror image
 #pragma unroll
-            for (int r = 0; r < TI; ++r)
-#pragma unroll
-                for (int c = 0; c < TJ; ++c) {
-                    const int i = i0 + r, j = j0 + c;
-                    if (i <= j) {
-                        Ob[i * LD + j] = acc[r][c];
-                        Ob[j * LD + i] = acc[r][c];
-                    }
+                for (int r = 0; r < TI; ++r) {
+                    double2* row = reinterpret_cast<double2*>(Gd + (i0 + r) * D + j0);
+                    row[0] = make_double2(acc[r][0], acc[r][1]);
+                    row[1] = make_double2(acc[r][2], acc[r][3]);
                 }
-        }
-    }
-    __syncthreads();
-    {
-        double* Gd = a.dEdS + e * DD;
 #pragma unroll
-        for (int q0 = 0; q0 < DD; q0 += NT) {
-            const int q = q0 + tid;
-            if (q < DD) Gd[q] = Ob[(q / D) * LD + (q % D)];
+                for (int c = 0; c < TJ; ++c)
+                    *reinterpret_cast<double2*>(Gd + (j0 + c) * D + i0) = make_double2(acc[0][c], acc[1][c]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < TI; ++r)
+#pragma unroll
+                    for (int c = 0; c < TJ; ++c) {
+                        const int i = i0 + r, j = j0 + c;
+                        if (i <= j) {
+                            Gd[i * D + j] = acc[r][c];
+                            if (i < j) Gd[j * D + i] = acc[r][c];
+                        }
+                    }
+            }
         }
     }
+    VGPA_STAMP(8);
 }
