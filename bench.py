@@ -122,7 +122,7 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        en = engine.esde(prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, True, False)
+        en = engine.esde(prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False)
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
@@ -157,7 +157,7 @@ def main():
 
     if rank == 0:
         total_units = world * P * N * args.steps
-        bytes_per_unit = 8 * (4 * D * D + 4 * D + 1)   # reads A,S,b,m; writes dEdS, Edf, dEdm, Ef, Esde_t
+        bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
         achieved = P * N * bytes_per_unit / (esde_ms * 1e-3) / 1e9
         line = {
             "metric": "free-energy+grad evals/sec (problems x timesteps), L96 D=40",

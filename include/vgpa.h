@@ -163,7 +163,7 @@ int vgpa_reduce_energy(int P, int N, int C, const double* x, const double* w,
  *   obs_idx (M) int32 time indices; obsY (M,d) [obsY_stride]; H (D,d);
  *   Ri (d,d) and Qi (d,d) as returned by chol_inv(R) (auxiliary/numerical.py:10-48);
  *   logconst = M * (d*log(2 pi) + log det R).  For D == 1: H, Ri are single
- *   values, Qi is unused.
+ *   values, Qi is unused.  work is caller-provided scratch of P*M doubles (D > 1).
  *   -> Eobs (P); dEobs_dm (P,N,D) (zeroed, then rows obs_idx filled);
  *      jumpS (D,D) = 0.5 H' Ri H (the value of dEobs_dS at every observed row).
  */
@@ -171,7 +171,7 @@ int vgpa_obs_terms(int P, int N, int D, int M, int d,
                    const double* m, const double* S,
                    const int* obs_idx, const double* obsY, int obsY_stride,
                    const double* H, const double* Ri, const double* Qi,
-                   double logconst,
+                   double logconst, double* work,
                    double* Eobs, double* dEobs_dm, double* jumpS, void* stream);
 
 /*
@@ -189,12 +189,17 @@ int vgpa_kl0(int P, int D, const double* m0, const double* S0,
  * Gradient of the Lagrangian w.r.t. A(t), b(t): replaces core/gradL_Ab.py:50
  * `gradL_Ab_1D` and :112 `gradL_Ab_nD` (the loop :156-173 and the dt scaling
  * :176-177).  SigInv (D,D) [sig_stride] is inv(Sigma) (1-D: 1/Sigma).
+ *   Edf may be NULL for D > 1: <df/dx> is then derived from the mean for
+ *   edf_system = VGPA_SYS_L96_UT (dynamics/sys_lorenz_96_ut.py:293-330) or a Lorenz-63
+ *   system (dynamics/sys_lorenz_63.py:227, needs theta (3) [theta_stride]), which saves
+ *   writing and re-reading a dense (P,N,D,D) array.
  *   -> gLA (P,N,D,D), gLb (P,N,D), already multiplied by dt.
  */
 int vgpa_grad_assemble(int P, int N, int D,
                        const double* A, const double* b, const double* m, const double* S,
                        const double* lam, const double* Psi,
                        const double* Ef, const double* Edf,
+                       int edf_system, const double* theta, int theta_stride,
                        const double* SigInv, int sig_stride, double dt, int flags,
                        double* gLA, double* gLb, void* stream);
 

@@ -323,3 +323,48 @@ def test_symmetric_scan_kernels_are_bitwise_the_general_ones(D, method):
         assert relerr(S1[p].cpu().numpy(), Sr) <= TOL and relerr(m1[p].cpu().numpy(), mr) <= TOL
         lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS[p], dt, method)
         assert relerr(P1[p].cpu().numpy(), Pr) <= TOL and relerr(l1[p].cpu().numpy(), lr) <= TOL
+
+
+@pytest.mark.parametrize("system,fname", [("l96_ut", "sys_l96_ut_d6.npz"), ("l96_ut", "sys_l96_ut_d40.npz"),
+                                          ("l63", "sys_l63.npz"), ("l63_ut", "sys_l63_ut.npz")])
+def test_gradient_with_implicit_drift_jacobian(system, fname):
+    """Skipping the dense <df/dx> array (the assembly kernel derives it from the
+    mean) must not change the gradient."""
+    import torch
+    from vgpa_amd import engine, _lib
+    g = load_golden(fname)
+    sde = sde_from_golden(g, "HEUN")
+    m0, S0 = initial_moments(g)
+    N, D = sde["N"], sde["D"]
+    A, b = orc.unpack_Ab(g["Ab"], N, D)
+    prob = engine.make_problem(_lib.SYSTEMS[system], sde, m0, S0, P=1)
+    Ad, bd = engine.to_dev(A[None]), engine.to_dev(b[None])
+    st_dense = engine.free_energy(prob, Ad, bd)
+    st_impl = engine.free_energy(prob, Ad, bd, want_edf=False)
+    assert st_impl.Edf is None and st_dense.Edf is not None
+    g1 = engine.gradient(prob, Ad, bd, st_dense)
+    g2 = engine.gradient(prob, Ad, bd, st_impl)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    got = np.concatenate((g2[0].reshape(-1).cpu().numpy(), g2[1].reshape(-1).cpu().numpy()))
+    assert relerr(got, g["HEUN.grad"]) <= TOL
+
+
+def test_observation_terms_with_dense_operators():
+    """Non-diagonal H and R (the reference's chol_inv quirk included) through the
+    per-observation kernel."""
+    from vgpa_amd.core import likelihood
+    rng = np.random.default_rng(77)
+    D, N = 7, 30
+    X = rng.standard_normal((D, D))
+    R = 0.5 * np.eye(D) + 0.1 * X.dot(X.T)
+    H = np.eye(D) + 0.2 * rng.standard_normal((D, D))
+    obsX = np.array([2, 3, 11, 19, 28])
+    sde = dict(D=D, N=N, dt=0.01, Rig=R, H=H, obsX=obsX, obsY=rng.standard_normal((5, D)), theta=8.0,
+               Sig=np.eye(D), ode_method="EULER")
+    m = rng.standard_normal((N, D))
+    S = 0.3 * np.eye(D)[None] + 0.05 * rng.standard_normal((N, D, D))
+    E, dm, dS, dR = likelihood.gauss(m, S, sde)
+    Er, dmr, dSr = orc.likelihood_gauss(m, S, sde)
+    assert abs(E - Er) <= TOL * abs(Er)
+    assert relerr(dm, dmr) <= TOL and relerr(dS, dSr) <= TOL
+    assert not dR.any()

@@ -1,8 +1,9 @@
 import ctypes, os, sys, numpy as np
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import torch
 from vgpa_amd import _lib
-dbg = ctypes.CDLL(os.path.join(os.getcwd(), "tools/diag/libvgpa_stamps.so"))
+dbg = ctypes.CDLL(os.path.join(ROOT, "tools/diag/libvgpa_stamps.so"))
 # point the binding at the diagnostic library
 for name, args in _lib.SIGNATURES.items():
     fn = getattr(dbg, name); fn.restype = ctypes.c_int; fn.argtypes = args

@@ -46,9 +46,10 @@ SIGNATURES = {
     "vgpa_esde_l96_ut": _ESDE_ARGS,
     "vgpa_reduce_energy": [_c_int, _c_int, _c_int, _ptr, _ptr, _c_dbl, _ptr, _ptr],
     "vgpa_obs_terms": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
-                       _c_dbl, _ptr, _ptr, _ptr, _ptr],
+                       _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr],
     "vgpa_kl0": [_c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _ptr],
-    "vgpa_grad_assemble": [_c_int, _c_int, _c_int] + [_ptr] * 9 + [_c_int, _c_dbl, _c_int, _ptr, _ptr, _ptr],
+    "vgpa_grad_assemble": [_c_int, _c_int, _c_int] + [_ptr] * 8 + [_c_int, _ptr, _c_int, _ptr, _c_int, _c_dbl, _c_int,
+                           _ptr, _ptr, _ptr],
 }
 EXPORTS = ["vgpa_version", "vgpa_last_error_string"] + list(SIGNATURES)
 

@@ -34,65 +34,78 @@ reduce_energy_kernel(int N, int C, const double* __restrict__ x, const double* _
 }
 
 // ---------------------------------------------------------------------------
-// Observation terms, D > 1: one wavefront per problem, observations in sequence.
-// core/likelihood.py@108-179.
+// Observation terms, D > 1: one wavefront per (observation, problem); the energy
+// contributions go to work[p][n] and are summed in a fixed order by
+// obs_finish_kernel.  core/likelihood.py@108-179.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 obs_terms_nd_kernel(int N, int D, int M, const double* __restrict__ m, const double* __restrict__ S,
                     const int* __restrict__ obs_idx, const double* __restrict__ obsY, int obsY_stride,
                     const double* __restrict__ H, const double* __restrict__ Ri, const double* __restrict__ Qi,
-                    double logconst, double* __restrict__ Eobs, double* __restrict__ dEobs_dm,
-                    double* __restrict__ jumpS) {
+                    double* __restrict__ work, double* __restrict__ dEobs_dm) {
     extern __shared__ double lds[];
     double* Wv = lds;          // W_n = y_n - m(t_n) H
     double* Tv = lds + D;      // Ri W_n
-    const int p = blockIdx.x, l = threadIdx.x;
+    const int n = blockIdx.x, p = blockIdx.y, l = threadIdx.x;
     const size_t DD = (size_t)D * D;
     const double* Y = obsY + (size_t)p * obsY_stride;
-    double e_acc = 0.0;        // per-lane share of sum_n (Z_n.Z_n + diag(Ri).diag(S_n))
-    for (int n = 0; n < M; ++n) {
-        const int tn = obs_idx[n];
-        const double* mt = m + ((size_t)p * N + tn) * D;
-        __syncthreads();
-        if (l < D) {
-            double hm = 0.0;
-            for (int i = 0; i < D; ++i) hm = fma(mt[i], H[i * D + l], hm);       // (m H)[l]
-            Wv[l] = Y[(size_t)n * D + l] - hm;
-        }
-        __syncthreads();
-        if (l < D) {
-            double z = 0.0, t = 0.0;
-            for (int j = 0; j < D; ++j) {
-                z = fma(Wv[j], Qi[l * D + j], z);                                 // (W Qi')[l]
-                t = fma(Ri[l * D + j], Wv[j], t);                                 // (Ri W)[l]
-            }
-            Tv[l] = t;
-            e_acc += z * z + Ri[l * D + l] * S[((size_t)p * N + tn) * DD + (size_t)l * D + l];
-        }
-        __syncthreads();
-        if (l < D) {
-            double gsum = 0.0;
-            for (int k = 0; k < D; ++k) gsum = fma(H[k * D + l], Tv[k], gsum);   // (H' Ri W)[l]
-            dEobs_dm[((size_t)p * N + tn) * D + l] = -gsum;
-        }
+    const int tn = obs_idx[n];
+    const double* mt = m + ((size_t)p * N + tn) * D;
+    if (l < D) {
+        double hm = 0.0;
+        for (int i = 0; i < D; ++i) hm = fma(mt[i], H[i * D + l], hm);           // (m H)[l]
+        Wv[l] = Y[(size_t)n * D + l] - hm;
     }
-    double tot = e_acc;
+    __syncthreads();
+    double e_l = 0.0;
+    if (l < D) {
+        double z = 0.0, t = 0.0;
+        for (int j = 0; j < D; ++j) {
+            z = fma(Wv[j], Qi[l * D + j], z);                                     // (W Qi')[l]
+            t = fma(Ri[l * D + j], Wv[j], t);                                     // (Ri W)[l]
+        }
+        Tv[l] = t;
+        e_l = z * z + Ri[l * D + l] * S[((size_t)p * N + tn) * DD + (size_t)l * D + l];
+    }
+    __syncthreads();
+    if (l < D) {
+        double gsum = 0.0;
+        for (int k = 0; k < D; ++k) gsum = fma(H[k * D + l], Tv[k], gsum);       // (H' Ri W)[l]
+        dEobs_dm[((size_t)p * N + tn) * D + l] = -gsum;
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
-    if (l == 0) Eobs[p] = 0.5 * (tot + logconst);
-    if (p == 0 && jumpS) {
-        // 0.5 H' Ri H
-        for (int q = l; q < (int)DD; q += 64) {
-            const int i = q / D, j = q % D;
-            double s = 0.0;
-            for (int a = 0; a < D; ++a) {
-                double rh = 0.0;
-                for (int c = 0; c < D; ++c) rh = fma(Ri[a * D + c], H[c * D + j], rh);
-                s = fma(H[a * D + i], rh, s);
-            }
-            jumpS[q] = 0.5 * s;
-        }
+    for (int off = 32; off >= 1; off >>= 1) e_l += __shfl_xor(e_l, off, 64);
+    if (l == 0) work[(size_t)p * M + n] = e_l;
+}
+
+// jumpS = 0.5 H' Ri H (one workgroup; the D x D product Ri H goes through LDS).
+__global__ void __launch_bounds__(256)
+obs_jump_kernel(int D, const double* __restrict__ H, const double* __restrict__ Ri, double* __restrict__ jumpS) {
+    extern __shared__ double lds[];   // RH[D][D]
+    const int DD = D * D;
+    for (int q = threadIdx.x; q < DD; q += blockDim.x) {
+        const int a = q / D, j = q % D;
+        double rh = 0.0;
+        for (int c = 0; c < D; ++c) rh = fma(Ri[a * D + c], H[c * D + j], rh);
+        lds[q] = rh;
     }
+    __syncthreads();
+    for (int q = threadIdx.x; q < DD; q += blockDim.x) {
+        const int i = q / D, j = q % D;
+        double s = 0.0;
+        for (int a = 0; a < D; ++a) s = fma(H[a * D + i], lds[a * D + j], s);
+        jumpS[q] = 0.5 * s;
+    }
+}
+
+// Eobs[p] = 0.5 (sum_n work[p][n] + logconst), observations in index order.
+__global__ void obs_finish_kernel(int P, int M, const double* __restrict__ work, double logconst,
+                                  double* __restrict__ Eobs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double s = 0.0;
+    for (int n = 0; n < M; ++n) s += work[(size_t)p * M + n];
+    Eobs[p] = 0.5 * (s + logconst);
 }
 
 // D == 1: one lane per problem.  core/likelihood.py@52-105 (the energy uses
@@ -237,6 +250,34 @@ __global__ void kl0_1d_kernel(int P, const double* __restrict__ m0, const double
     KL0[p] = -log(S0[p]) - 0.5 * (1.0 - log(t0)) + 0.5 / t0 * (z0 * z0 + S0[p]);
 }
 
+// <df/dx>[i][j] derived from the mean instead of read from memory.
+// Lorenz-96: row i is filled in the order [i] = -1, [i+1] = m[i-1], [i-2] = -m[i-1],
+// [i-1] = m[i+1] - m[i-2] (dynamics/sys_lorenz_96_ut.py:317-328; later entries win
+// when indices collide for D < 4).  Lorenz-63: dynamics/sys_lorenz_63.py:227.
+__device__ inline double edf_implicit(int system, int D, int i, int j, const double* mv, const double* th) {
+    if (system == VGPA_SYS_L96_UT) {
+        const int jf1 = (i + 1) % D, jb1 = (i + D - 1) % D, jb2 = (i + 2 * D - 2) % D;
+        double v = 0.0;
+        if (j == i) v = -1.0;
+        if (j == jf1) v = mv[jb1];
+        if (j == jb2) v = -mv[jb1];
+        if (j == jb1) v = mv[jf1] - mv[jb2];
+        return v;
+    }
+    // Lorenz-63 (analytic or unscented): th = (sigma, rho, beta)
+    switch (i * 3 + j) {
+        case 0: return -th[0];
+        case 1: return th[0];
+        case 2: return 0.0;
+        case 3: return th[1] - mv[2];
+        case 4: return -1.0;
+        case 5: return -mv[0];
+        case 6: return mv[1];
+        case 7: return mv[0];
+        default: return -th[2];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Gradient assembly, D > 1: one workgroup per (problem, step).
 // core/gradL_Ab.py:156-177.  gLA = dt ( [SigInv (Edf + A) - 2 Psi] S - s1 - s2 ).
@@ -247,7 +288,8 @@ __global__ void __launch_bounds__(512)
 grad_assemble_nd_kernel(int N, int D, const double* __restrict__ A, const double* __restrict__ b,
                         const double* __restrict__ m, const double* __restrict__ S,
                         const double* __restrict__ lam, const double* __restrict__ Psi,
-                        const double* __restrict__ Ef, const double* __restrict__ Edf,
+                        const double* __restrict__ Ef, const double* __restrict__ Edf, int edf_system,
+                        const double* __restrict__ theta, int theta_stride,
                         const double* __restrict__ SigInv, int sig_stride, int sig_diag, double dt, int flags,
                         double* __restrict__ gLA, double* __restrict__ gLb) {
     extern __shared__ double lds[];
@@ -267,7 +309,8 @@ grad_assemble_nd_kernel(int N, int D, const double* __restrict__ A, const double
     const double* Ae = A + e * DD;
     const double* Se = S + e * DD;
     const double* Pe = Psi + e * DD;
-    const double* Ee = Edf + e * DD;
+    const double* Ee = Edf ? Edf + e * DD : nullptr;
+    const double* th = theta ? theta + (size_t)p * theta_stride : nullptr;
     const double* SI = SigInv + (size_t)p * sig_stride;
     for (int q = tid; q < (int)DD; q += nth) {
         const int o = (q / D) * LD + (q % D);
@@ -310,12 +353,13 @@ grad_assemble_nd_kernel(int N, int D, const double* __restrict__ A, const double
     if (sig_diag) {
         for (int q = tid; q < (int)DD; q += nth) {
             const int i = q / D, o = i * LD + (q % D);
-            Xm[o] = SI[(size_t)i * D + i] * (Ee[q] + Xm[o]) - 2.0 * Pe[q];
+            const double ed = Ee ? Ee[q] : edf_implicit(edf_system, D, i, q % D, mv, th);
+            Xm[o] = SI[(size_t)i * D + i] * (ed + Xm[o]) - 2.0 * Pe[q];
         }
     } else {
         for (int q = tid; q < (int)DD; q += nth) {
             const int o = (q / D) * LD + (q % D);
-            Ym[o] = Ee[q] + Xm[o];
+            Ym[o] = (Ee ? Ee[q] : edf_implicit(edf_system, D, q / D, q % D, mv, th)) + Xm[o];
         }
         __syncthreads();
         for (int q = tid; q < (int)DD; q += nth) {
@@ -362,6 +406,140 @@ grad_assemble_nd_kernel(int N, int D, const double* __restrict__ A, const double
     }
 }
 
+// Compile-time-D version for diagonal SigInv: 16-byte LDS reads, unrolled product,
+// 16-byte global stores.  EDF_IMPLICIT derives <df/dx> of Lorenz-96 from the mean.
+template <int D, bool EDF_IMPLICIT>
+__global__ void __launch_bounds__(256)
+grad_assemble_tiled_kernel(int N, const double* __restrict__ A, const double* __restrict__ b,
+                           const double* __restrict__ m, const double* __restrict__ S,
+                           const double* __restrict__ lam, const double* __restrict__ Psi,
+                           const double* __restrict__ Ef, const double* __restrict__ Edf,
+                           const double* __restrict__ SigInv, int sig_stride, double dt, int flags,
+                           double* __restrict__ gLA, double* __restrict__ gLb) {
+    constexpr int LD = D + 2, MS = D * LD, DD = D * D, NT = 256;
+    constexpr int NTJ = D / GJ, NTI = D / GI;
+    static_assert(NTI * NTJ <= NT && D % 4 == 0, "one 2x4 tile per thread");
+    extern __shared__ double lds[];
+    double* Xm = lds;             // A, then diag(SigInv) (Edf + A) - 2 Psi
+    double* Sm = lds + MS;        // S(t)
+    double* mv = lds + 2 * MS;
+    double* lv = mv + D;
+    double* dbv = lv + D;
+    double* siv = dbv + D;
+    double* sc = siv + D;         // s1 + s2
+    const size_t e = blockIdx.x;  // p * N + t
+    const int p = (int)(e / N);
+    const int tid = threadIdx.x;
+    const double2* Ae = reinterpret_cast<const double2*>(A + e * DD);
+    const double2* Se = reinterpret_cast<const double2*>(S + e * DD);
+    const double2* Pe = reinterpret_cast<const double2*>(Psi + e * DD);
+    const double2* Ee = reinterpret_cast<const double2*>(Edf + (EDF_IMPLICIT ? 0 : e * DD));
+    const double* SI = SigInv + (size_t)p * sig_stride;
+    double2 pre_p[4], pre_e[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = tid + r * NT;
+        const int qc = q < DD / 2 ? q : DD / 2 - 1;          // clamped: loads carry no predicate
+        const int o = ((2 * qc) / D) * LD + ((2 * qc) % D);
+        const double2 av = Ae[qc], sv = Se[qc];
+        pre_p[r] = Pe[qc];
+        if (!EDF_IMPLICIT) pre_e[r] = Ee[qc];
+        if (q < DD / 2) {
+            *reinterpret_cast<double2*>(Xm + o) = av;
+            *reinterpret_cast<double2*>(Sm + o) = sv;
+        }
+    }
+    if (tid < D) {
+        mv[tid] = m[e * D + tid];
+        lv[tid] = lam[e * D + tid];
+        siv[tid] = SI[(size_t)tid * D + tid];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double s12 = 0.0;
+        if (tid < D) {
+            double am0 = 0.0, am1 = 0.0;
+#pragma unroll 5
+            for (int k = 0; k < D; k += 2) {
+                const double2 av = *reinterpret_cast<const double2*>(Xm + tid * LD + k);
+                am0 = fma(av.x, mv[k], am0);
+                am1 = fma(av.y, mv[k + 1], am1);
+            }
+            const double u = -Ef[e * D + tid] - (am0 + am1) + b[e * D + tid];
+            const double d = u * siv[tid];
+            dbv[tid] = d;
+            gLb[e * D + tid] = dt * (d + lv[tid]);
+            s12 = d * mv[tid] + lv[tid] * mv[tid];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s12 += __shfl_xor(s12, off, 64);
+        if (tid == 0) sc[0] = s12;
+    }
+    __syncthreads();   // every thread has read its share of A before X overwrites it
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = tid + r * NT;
+        if (q < DD / 2) {
+            const int i = (2 * q) / D, j = (2 * q) % D, o = i * LD + j;
+            const double2 av = *reinterpret_cast<const double2*>(Xm + o);
+            double e0, e1;
+            if (EDF_IMPLICIT) {
+                e0 = edf_implicit(VGPA_SYS_L96_UT, D, i, j, mv, nullptr);
+                e1 = edf_implicit(VGPA_SYS_L96_UT, D, i, j + 1, mv, nullptr);
+            } else {
+                e0 = pre_e[r].x;
+                e1 = pre_e[r].y;
+            }
+            const double si = siv[i];
+            *reinterpret_cast<double2*>(Xm + o) =
+                make_double2(si * (e0 + av.x) - 2.0 * pre_p[r].x, si * (e1 + av.y) - 2.0 * pre_p[r].y);
+        }
+    }
+    __syncthreads();
+    if (tid < NTI * NTJ) {
+        const int i0 = (tid / NTJ) * GI, j0 = (tid % NTJ) * GJ;
+        double acc[GI][GJ] = {};
+        const double* x0 = Xm + i0 * LD;
+        const double* x1 = x0 + LD;
+        const double* sr = Sm + j0;
+#pragma unroll 5
+        for (int k = 0; k < D; k += 2) {
+            const double2 a0 = *reinterpret_cast<const double2*>(x0 + k);
+            const double2 a1 = *reinterpret_cast<const double2*>(x1 + k);
+            const double2 p0 = *reinterpret_cast<const double2*>(sr + k * LD);
+            const double2 p1 = *reinterpret_cast<const double2*>(sr + k * LD + 2);
+            const double2 q0 = *reinterpret_cast<const double2*>(sr + (k + 1) * LD);
+            const double2 q1 = *reinterpret_cast<const double2*>(sr + (k + 1) * LD + 2);
+            const double ps[GJ] = {p0.x, p0.y, p1.x, p1.y}, qs[GJ] = {q0.x, q0.y, q1.x, q1.y};
+#pragma unroll
+            for (int c = 0; c < GJ; ++c) {
+                acc[0][c] = fma(a0.x, ps[c], acc[0][c]);
+                acc[1][c] = fma(a1.x, ps[c], acc[1][c]);
+            }
+#pragma unroll
+            for (int c = 0; c < GJ; ++c) {
+                acc[0][c] = fma(a0.y, qs[c], acc[0][c]);
+                acc[1][c] = fma(a1.y, qs[c], acc[1][c]);
+            }
+        }
+        const double s12 = sc[0];
+        double out[GI][GJ];
+#pragma unroll
+        for (int a = 0; a < GI; ++a)
+#pragma unroll
+            for (int c = 0; c < GJ; ++c) {
+                const double corr = (flags & VGPA_GRAD_OUTER) ? (dbv[i0 + a] * mv[j0 + c] + lv[i0 + a] * mv[j0 + c]) : s12;
+                out[a][c] = dt * (acc[a][c] - corr);
+            }
+#pragma unroll
+        for (int a = 0; a < GI; ++a) {
+            double2* row = reinterpret_cast<double2*>(gLA + e * DD + (size_t)(i0 + a) * D + j0);
+            row[0] = make_double2(out[a][0], out[a][1]);
+            row[1] = make_double2(out[a][2], out[a][3]);
+        }
+    }
+}
+
 // core/gradL_Ab.py:85-106.
 __global__ void grad_assemble_1d_kernel(size_t total, int N, const double* __restrict__ A, const double* __restrict__ b,
                                         const double* __restrict__ m, const double* __restrict__ S,
@@ -404,12 +582,12 @@ extern "C" int vgpa_reduce_energy(int P, int N, int C, const double* x, const do
 
 extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m, const double* S,
                               const int* obs_idx, const double* obsY, int obsY_stride, const double* H,
-                              const double* Ri, const double* Qi, double logconst, double* Eobs,
+                              const double* Ri, const double* Qi, double logconst, double* work, double* Eobs,
                               double* dEobs_dm, double* jumpS, void* stream) {
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1 && M >= 0, "vgpa_obs_terms: bad sizes P=%d N=%d D=%d M=%d", P, N, D, M);
     VGPA_REQUIRE(d == D, "vgpa_obs_terms: observation dimension d=%d must equal D=%d", d, D);
     VGPA_REQUIRE(m && S && (M == 0 || (obs_idx && obsY)) && H && Ri && Eobs && dEobs_dm, "vgpa_obs_terms: null pointer argument");
-    VGPA_REQUIRE(D == 1 || Qi, "vgpa_obs_terms: Qi is required for D > 1");
+    VGPA_REQUIRE(D == 1 || (Qi && work), "vgpa_obs_terms: Qi and work are required for D > 1");
     VGPA_REQUIRE(obsY_stride == 0 || obsY_stride == M * d, "vgpa_obs_terms: obsY_stride must be 0 or M*d");
     if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_obs_terms: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
     if (P == 0) return VGPA_OK;
@@ -422,8 +600,12 @@ extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m
                            obsY_stride, H, Ri, logconst, Eobs, dEobs_dm, jumpS);
     } else {
         const size_t lds = sizeof(double) * 2 * D;
-        hipLaunchKernelGGL(obs_terms_nd_kernel, dim3(P), dim3(64), lds, st, N, D, M, m, S, obs_idx, obsY,
-                           obsY_stride, H, Ri, Qi, logconst, Eobs, dEobs_dm, jumpS);
+        if (M > 0)
+            hipLaunchKernelGGL(obs_terms_nd_kernel, dim3(M, P), dim3(64), lds, st, N, D, M, m, S, obs_idx, obsY,
+                               obsY_stride, H, Ri, Qi, work, dEobs_dm);
+        if (jumpS)
+            hipLaunchKernelGGL(obs_jump_kernel, dim3(1), dim3(256), sizeof(double) * D * D, st, D, H, Ri, jumpS);
+        hipLaunchKernelGGL(obs_finish_kernel, dim3((P + 63) / 64), dim3(64), 0, st, P, M, work, logconst, Eobs);
     }
     return vgpa::check_launch("vgpa_obs_terms");
 }
@@ -451,12 +633,18 @@ extern "C" int vgpa_kl0(int P, int D, const double* m0, const double* S0, const 
 
 extern "C" int vgpa_grad_assemble(int P, int N, int D, const double* A, const double* b, const double* m,
                                   const double* S, const double* lam, const double* Psi, const double* Ef,
-                                  const double* Edf, const double* SigInv, int sig_stride, double dt, int flags,
+                                  const double* Edf, int edf_system, const double* theta, int theta_stride,
+                                  const double* SigInv, int sig_stride, double dt, int flags,
                                   double* gLA, double* gLb, void* stream) {
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_grad_assemble: bad sizes P=%d N=%d D=%d", P, N, D);
-    VGPA_REQUIRE(A && b && m && S && lam && Psi && Ef && Edf && SigInv && gLA && gLb, "vgpa_grad_assemble: null pointer argument");
+    VGPA_REQUIRE(A && b && m && S && lam && Psi && Ef && SigInv && gLA && gLb, "vgpa_grad_assemble: null pointer argument");
     VGPA_REQUIRE(sig_stride == 0 || sig_stride == D * D, "vgpa_grad_assemble: sig_stride must be 0 or D*D");
     VGPA_REQUIRE((size_t)P * N < 0x7fffffffull, "vgpa_grad_assemble: P*N too large");
+    if (!Edf) {
+        VGPA_REQUIRE(D > 1, "vgpa_grad_assemble: Edf is required for D == 1");
+        VGPA_REQUIRE(edf_system == VGPA_SYS_L96_UT || ((edf_system == VGPA_SYS_L63 || edf_system == VGPA_SYS_L63_UT) && D == 3 && theta),
+                     "vgpa_grad_assemble: Edf is NULL and edf_system=%d cannot be derived from the mean", edf_system);
+    }
     if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_grad_assemble: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
     const size_t total = (size_t)P * N;
     if (total == 0) return VGPA_OK;
@@ -467,10 +655,25 @@ extern "C" int vgpa_grad_assemble(int P, int N, int D, const double* A, const do
                            A, b, m, S, lam, Psi, Ef, Edf, SigInv, sig_stride, dt, gLA, gLb);
     } else {
         const int sig_diag = (flags & VGPA_GRAD_SIGINV_DIAG) ? 1 : 0;
-        const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 4 * D + 2);
-        allow_lds(grad_assemble_nd_kernel, lds);
-        hipLaunchKernelGGL(grad_assemble_nd_kernel, dim3((unsigned)total), dim3(tile_threads(D)), lds, st, N, D, A, b, m,
-                           S, lam, Psi, Ef, Edf, SigInv, sig_stride, sig_diag, dt, flags, gLA, gLb);
+        const bool implicit96 = !Edf && edf_system == VGPA_SYS_L96_UT;
+        if (sig_diag && (D == 40 || D == 16) && (Edf || implicit96)) {
+            const size_t lds = sizeof(double) * ((size_t)2 * D * (D + 2) + 4 * D + 2);
+#define VGPA_LAUNCH_GT(DD_, IMP)                                                                              \
+    do {                                                                                                      \
+        allow_lds(grad_assemble_tiled_kernel<DD_, IMP>, lds);                                                 \
+        hipLaunchKernelGGL((grad_assemble_tiled_kernel<DD_, IMP>), dim3((unsigned)total), dim3(256), lds, st, N, A, b, \
+                           m, S, lam, Psi, Ef, Edf ? Edf : A, SigInv, sig_stride, dt, flags, gLA, gLb);      \
+    } while (0)
+            if (D == 40) { if (implicit96) VGPA_LAUNCH_GT(40, true); else VGPA_LAUNCH_GT(40, false); }
+            else { if (implicit96) VGPA_LAUNCH_GT(16, true); else VGPA_LAUNCH_GT(16, false); }
+#undef VGPA_LAUNCH_GT
+        } else {
+            const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 4 * D + 2);
+            allow_lds(grad_assemble_nd_kernel, lds);
+            hipLaunchKernelGGL(grad_assemble_nd_kernel, dim3((unsigned)total), dim3(tile_threads(D)), lds, st, N, D, A,
+                               b, m, S, lam, Psi, Ef, Edf, edf_system, theta, theta_stride, SigInv, sig_stride,
+                               sig_diag, dt, flags, gLA, gLb);
+        }
     }
     return vgpa::check_launch("vgpa_grad_assemble");
 }

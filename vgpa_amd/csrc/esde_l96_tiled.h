@@ -37,6 +37,10 @@ struct L96Tiled {
     static constexpr int NT = 256;
     static_assert(D % NB == 0, "D must be a multiple of 8");
     static_assert(NTI * NTJ <= NT, "one register tile per thread");
+    // Tiles (ti, tj) of the symmetric output that touch the upper triangle, listed by
+    // column tile: column tile tj has 2 tj + 2 of them (2 tj + 1 when clipped), so tile
+    // number q sits in the column tile with tj (tj + 1) <= q.
+    static constexpr int NUPPER = NTJ * (NTJ + 1) - ((2 * NTJ > NTI) ? (2 * NTJ - NTI) : 0);
     static constexpr int XB = 2 * NPAIR * D + (HYPER ? NTJ * D : 0);
     // Lm, Am | partial sums | 8x8 inverses | per-wave 8x8 scratch | vectors | scalars
     static constexpr int LDS_DOUBLES = 2 * MS + XB + NBLK * NB * NB + 4 * NB * NB + 6 * D + 8;
@@ -206,12 +210,9 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
             for (int k = 0; k < NB; ++k) {
                 piv[k] = readlane_f64(s[k], k);
                 ok = ok && (piv[k] > 0.0);
-                const double qk = rcp_refined(piv[k]);
+                const double tk = s[k] * rcp_refined(piv[k]);   // row k over its pivot
 #pragma unroll
-                for (int i = k + 1; i < NB; ++i) {
-                    const double mi = readlane_f64(s[k], i) * qk;
-                    s[i] = fma(-mi, s[k], s[i]);
-                }
+                for (int i = k + 1; i < NB; ++i) s[i] = fma(-readlane_f64(tk, i), s[k], s[i]);
             }
             double rinv[NB];
 #pragma unroll
@@ -475,10 +476,16 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
 
     VGPA_STAMP(7);
     // ---- phase 7: dEsde/dS = W' V, upper tiles, mirrored -----------------------
-    if (tid < NTI * NTJ) {
-        const int ti = tid / NTJ, tj = tid % NTJ;
+    if (tid < C::NUPPER) {
+        // tile number -> (ti, tj): column tile tj starts at tile tj (tj + 1); long k-loops
+        // (small tj) come first so the two active wavefronts see similar trip counts
+        // within themselves.
+        int tj = 0;
+#pragma unroll
+        for (int q = 1; q < NTJ; ++q) tj += (tid >= q * (q + 1)) ? 1 : 0;
+        const int ti = tid - tj * (tj + 1);
         const int i0 = ti * TI, j0 = tj * TJ;
-        if (i0 <= j0 + TJ - 1) {
+        {
             double acc[TI][TJ] = {};
             const int k0 = (i0 > j0) ? i0 : j0;
 #pragma unroll 4

@@ -310,8 +310,9 @@ def obs_terms(prob, m, S):
     jumpS = torch.empty((D, D) if D > 1 else (1,), dtype=F64, device=m.device)
     d = prob.obsY.shape[-1]
     ystride = prob.M * d if (prob.obsY.dim() == 3 and P > 1) else 0
+    work = torch.empty((P, max(prob.M, 1)), dtype=F64, device=m.device)
     call("vgpa_obs_terms", P, N, D, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
-         _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(Eobs), _p(dm), _p(jumpS), _stream())
+         _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(work), _p(Eobs), _p(dm), _p(jumpS), _stream())
     return Eobs, dm, jumpS
 
 
@@ -327,12 +328,15 @@ def kl0(prob):
 
 
 def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False):
-    """vgpa_grad_assemble -> gLA (like A), gLb (like b), already times dt."""
+    """vgpa_grad_assemble -> gLA (like A), gLb (like b), already times dt.  With
+    ``Edf=None`` the kernel derives <df/dx> from the mean (Lorenz systems only)."""
     P, N, D = prob.P, prob.N, prob.D
     gLA = torch.empty_like(A)
     gLb = torch.empty_like(b)
     flags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
+    n_theta = 3 if prob.system in (_lib.SYS_L63, _lib.SYS_L63_UT) else 1
     call("vgpa_grad_assemble", P, N, D, _p(A), _p(b), _p(m), _p(S), _p(lam), _p(Psi), _p(Ef), _p(Edf),
+         prob.system, _p(prob.theta), _par_stride(prob.theta, P, n_theta),
          _p(prob.SigInv), _par_stride(prob.SigInv, P, D * D), float(prob.dt), flags, _p(gLA), _p(gLb), _stream())
     return gLA, gLb
 
@@ -340,11 +344,11 @@ def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False):
 # ---------------------------------------------------------------------------
 # the evaluation
 # ---------------------------------------------------------------------------
-def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hyper=True):
+def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hyper=True, want_edf=True):
     """The ``energy_mode`` contract on device: per-step kernel + time reductions.
     Returns a dict with Esde (P,), Ef, Edf, dEdm, dEdS, dth, dSig, status."""
     D = 1 if A.dim() == 2 else A.shape[-1]
-    out = esde(system, A, b, m, S, sig_inv_diag, theta, True, want_hyper)
+    out = esde(system, A, b, m, S, sig_inv_diag, theta, want_edf, want_hyper)
     out["Esde"] = reduce_energy(out["Esde_t"], w, dt)
     if want_hyper:
         tr_th = reduce_energy(out["dth_t"], w, dt)
@@ -402,15 +406,17 @@ class State:
     dSig: Optional[torch.Tensor] = None
 
 
-def free_energy(prob, A, b, want_hyper=False):
-    """core/varFreeEnergy.py:80-111 for a batch: returns a State with F (P,)."""
+def free_energy(prob, A, b, want_hyper=False, want_edf=True):
+    """core/varFreeEnergy.py:80-111 for a batch: returns a State with F (P,).
+    ``want_edf=False`` (Lorenz systems) skips the dense <df/dx> array; ``gradient``
+    then lets the assembly kernel derive it from the mean."""
     m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
     Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
     if prob.system < 0:
         en = _host_energy(prob, A, b, m, S)
     else:
         en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w,
-                          prob.dt, want_hyper)
+                          prob.dt, want_hyper, want_edf=want_edf or prob.D == 1)
     sym = prob.sym_jump and prob.system >= 0 and esde_output_is_symmetric(prob.system, prob.D)
     lam, Psi = bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
                         obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym)
