@@ -98,13 +98,17 @@ int vgpa_fwd_scan(int method, int P, int N, int D,
  *   [jumpS_stride] added at every row t with obs_flag[t] != 0 (obs_flag is (N)
  *   int32, shared by all problems).  Both NULL means no covariance jumps.
  *   flags: VGPA_SCAN_SYMMETRIC or 0.
- *   -> lam_out (P,N,D), Psi_out (P,N,D,D); row N-1 is zero.
+ *   lam_last (P,D), Psi_last (P,D,D): state of row N-1; NULL means zero, which is
+ *   what the reference starts from.  A time window of a longer scan passes the row it
+ *   received from the window after it.
+ *   -> lam_out (P,N,D), Psi_out (P,N,D,D); row N-1 holds the terminal state.
  */
 int vgpa_bwd_scan(int method, int P, int N, int D,
                   const double* A, const double* dEsde_dm, const double* dEsde_dS,
                   const double* dEobs_dm, const double* dEobs_dS,
                   const int* obs_flag, const double* jumpS, int jumpS_stride,
-                  double dt, int flags, double* lam_out, double* Psi_out, void* stream);
+                  double dt, int flags, const double* lam_last, const double* Psi_last,
+                  double* lam_out, double* Psi_out, void* stream);
 
 /*
  * Per-time-step expected SDE energy and its gradients: replaces the loop body of

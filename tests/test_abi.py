@@ -48,7 +48,7 @@ def test_bad_arguments_are_rejected_without_a_device():
     with pytest.raises(ValueError, match="Unknown method of integration"):
         _lib.call("vgpa_fwd_scan", 7, 1, 4, 3, one, one, one, one, one, 0, 0.01, 0, one, one, None)
     with pytest.raises(ValueError, match="Unknown method of integration"):
-        _lib.call("vgpa_bwd_scan", -1, 1, 4, 3, one, one, one, one, None, None, None, 0, 0.01, 0, one, one, None)
+        _lib.call("vgpa_bwd_scan", -1, 1, 4, 3, one, one, one, one, None, None, None, 0, 0.01, 0, None, None, one, one, None)
     with pytest.raises(_lib.VgpaError, match="null pointer"):
         _lib.call("vgpa_fwd_scan", 0, 1, 4, 3, None, one, one, one, one, 0, 0.01, 0, one, one, None)
     with pytest.raises(_lib.VgpaError, match="exceeds VGPA_MAX_D"):

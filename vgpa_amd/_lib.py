@@ -37,7 +37,7 @@ SIGNATURES = {
     "vgpa_fwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl, _c_int,
                       _ptr, _ptr, _ptr],
     "vgpa_bwd_scan": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl,
-                      _c_int, _ptr, _ptr, _ptr],
+                      _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "vgpa_esde": [_c_int] + _ESDE_ARGS,
     "vgpa_esde_ou": _ESDE_ARGS,
     "vgpa_esde_dw": _ESDE_ARGS,

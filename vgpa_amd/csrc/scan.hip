@@ -562,6 +562,7 @@ bwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* _
                    const double* __restrict__ dEdS, const double* __restrict__ jm,
                    const double* __restrict__ jS_dense, const int* __restrict__ obs_flag,
                    const double* __restrict__ jumpS, int jumpS_stride, double dt,
+                   const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
                    double* __restrict__ lam_out, double* __restrict__ Psi_out) {
     extern __shared__ double lds[];
     using G = NdGeom<DT>;
@@ -585,14 +586,15 @@ bwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* _
     if (!jSd && jumpS && obs_flag) load_tile(g, jumpS + (size_t)p * jumpS_stride, jt);
     else { TILE_FOR(a, c) jt[a][c] = 0.0; }
 
-    double s[TI][TJ];   // Psi[t]
-    TILE_FOR(a, c) s[a][c] = 0.0;
-    double lv = 0.0;    // lam[t][vi]
+    double s[TI][TJ];   // Psi[t]: zero at the last row unless a terminal state is given
+    if (Psi_last) load_tile(g, Psi_last + (size_t)p * DD, s);
+    else { TILE_FOR(a, c) s[a][c] = 0.0; }
+    double lv = (lam_last && g.vi >= 0) ? lam_last[(size_t)p * D + g.vi] : 0.0;    // lam[t][vi]
     store_tile_global(g, Po + (size_t)(N - 1) * DD, s);
     store_tile_lds(g, XBUF(0), s);
     if (g.vi >= 0) {
-        lo[(size_t)(N - 1) * D + g.vi] = 0.0;
-        XVEC(0)[g.vi] = 0.0;
+        lo[(size_t)(N - 1) * D + g.vi] = lv;
+        XVEC(0)[g.vi] = lv;
     }
     load_matrix_lds(g, Ap + (size_t)(N - 1) * DD, ABUF(0));
     // Register prefetch two steps deep: set A holds row t-1, set B holds row t-2.
@@ -790,6 +792,7 @@ __global__ void bwd_scan_1d_kernel(int P, int N, const double* __restrict__ A, c
                                    const double* __restrict__ dEdS, const double* __restrict__ jm,
                                    const double* __restrict__ jS_dense, const int* __restrict__ obs_flag,
                                    const double* __restrict__ jumpS, int jumpS_stride, double dt,
+                                   const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
                                    double* __restrict__ lam_out, double* __restrict__ Psi_out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -802,9 +805,9 @@ __global__ void bwd_scan_1d_kernel(int P, int N, const double* __restrict__ A, c
     double* lo = lam_out + (size_t)p * N;
     double* Po = Psi_out + (size_t)p * N;
     const double h = 0.5 * dt;
-    double lam = 0.0, Psi = 0.0;
-    lo[N - 1] = 0.0;
-    Po[N - 1] = 0.0;
+    double lam = lam_last ? lam_last[p] : 0.0, Psi = Psi_last ? Psi_last[p] : 0.0;
+    lo[N - 1] = lam;
+    Po[N - 1] = Psi;
     double At = Ap[N - 1], gmt = gm[N - 1], gSt = gS[N - 1];
     for (int t = N - 1; t >= 1; --t) {
         const double Ak_ = Ap[t - 1], gmp = gm[t - 1], gSp = gS[t - 1];
@@ -883,11 +886,11 @@ void launch_fwd(int P, int N, int D, const double* A, const double* b, const dou
 template <int METHOD, int DT, bool SYM>
 void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                 const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
-                double* lam_out, double* Psi_out, hipStream_t st) {
+                const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
     const size_t lds = nd_lds_bytes(D, DT > 0, METHOD, SYM);
     allow_lds(bwd_scan_nd_kernel<METHOD, DT, SYM>, lds);
     hipLaunchKernelGGL((bwd_scan_nd_kernel<METHOD, DT, SYM>), dim3(P), dim3(nd_threads(D, DT > 0)), lds, st, N, D, A, dEdm,
-                       dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_out, Psi_out);
+                       dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
 }
 
 // Expand (method, D, symmetric) into the template instance.
@@ -938,6 +941,7 @@ extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, c
 extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, const double* dEsde_dm,
                              const double* dEsde_dS, const double* dEobs_dm, const double* dEobs_dS,
                              const int* obs_flag, const double* jumpS, int jumpS_stride, double dt, int flags,
+                             const double* lam_last, const double* Psi_last,
                              double* lam_out, double* Psi_out, void* stream) {
     VGPA_REQUIRE(method >= VGPA_EULER && method <= VGPA_RK4, "vgpa_bwd_scan: Unknown method of integration (%d)", method);
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_bwd_scan: bad sizes P=%d N=%d D=%d", P, N, D);
@@ -948,7 +952,7 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
     hipStream_t st = vgpa::as_stream(stream);
     if (D == 1) {
         const int bs = 64, grid = (P + bs - 1) / bs;
-#define LAUNCH1(M) hipLaunchKernelGGL(bwd_scan_1d_kernel<M>, dim3(grid), dim3(bs), 0, st, P, N, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS, jumpS_stride, dt, lam_out, Psi_out)
+#define LAUNCH1(M) hipLaunchKernelGGL(bwd_scan_1d_kernel<M>, dim3(grid), dim3(bs), 0, st, P, N, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out)
         switch (method) {
             case VGPA_EULER: LAUNCH1(VGPA_EULER); break;
             case VGPA_HEUN: LAUNCH1(VGPA_HEUN); break;
@@ -958,7 +962,7 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
 #undef LAUNCH1
     } else {
         VGPA_DISPATCH_SCAN(launch_bwd, P, N, D, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS,
-                           jumpS_stride, dt, lam_out, Psi_out, st);
+                           jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out, st);
     }
     return vgpa::check_launch("vgpa_bwd_scan");
 }

@@ -247,9 +247,11 @@ def fwd_scan(method, A, b, m0, S0, Sigma, dt, symmetric=None):
     return m, S
 
 
-def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, jumpS=None, symmetric=False):
+def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, jumpS=None, symmetric=False,
+             lam_last=None, Psi_last=None):
     """vgpa_bwd_scan -> lam, Psi.  ``symmetric`` promises exactly symmetric dEdS and
-    jumps (see VGPA_SCAN_SYMMETRIC)."""
+    jumps (see VGPA_SCAN_SYMMETRIC); ``lam_last`` / ``Psi_last`` give the state of the
+    last row (zero when omitted)."""
     P, N = A.shape[0], A.shape[1]
     D = 1 if A.dim() == 2 else A.shape[-1]
     lam = torch.empty_like(dEdm)
@@ -259,7 +261,7 @@ def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, 
         jstride = D * D
     call("vgpa_bwd_scan", method, P, N, D, _p(A), _p(dEdm), _p(dEdS), _p(dEobs_dm), _p(dEobs_dS),
          _p(obs_flag), _p(jumpS), jstride, float(dt), _lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0,
-         _p(lam), _p(Psi), _stream())
+         _p(lam_last), _p(Psi_last), _p(lam), _p(Psi), _stream())
     return lam, Psi
 
 
