@@ -174,8 +174,10 @@ def fwd_scan(A, b, m0, S0, Sigma, dt, method="EULER"):
     return m, S
 
 
-def bwd_scan(A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, dt, method="EULER"):
-    """core/bwd_ode.py:50-563."""
+def bwd_scan(A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, dt, method="EULER", lam_last=None, Psi_last=None):
+    """core/bwd_ode.py:50-563.  The reference starts from lam = Psi = 0 at the last
+    row; ``lam_last`` / ``Psi_last`` replace that start so that tests can check a scan
+    cut into time windows."""
     method = method.upper()
     if method not in METHODS:
         raise ValueError("Unknown method of integration")
@@ -192,6 +194,9 @@ def bwd_scan(A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, dt, method="EULER"):
         Psi = np.zeros((N, D, D))
         fl = lambda dEdm, At, lt: -dEdm + lt.dot(At.T)       # noqa: E731 bwd_ode.py:42
         fp = lambda dEdS, At, Pt: -dEdS + Pt.dot(At) + At.T.dot(Pt)  # noqa: E731 bwd_ode.py:43
+    if lam_last is not None:
+        lam[N - 1] = lam_last
+        Psi[N - 1] = Psi_last
     h = 0.5 * dt
     for t in range(N - 1, 0, -1):
         At, lt, Pt = A[t], lam[t], Psi[t]
