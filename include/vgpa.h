@@ -53,8 +53,9 @@ extern "C" {
 #define VGPA_ST_CHOL_FALLBACK 1  /* chol((D+k)S) failed; diagonal fallback of
                                     auxiliary/numerical.py:201-202 was used     */
 #define VGPA_ST_CHOL_FAILED   2  /* the fallback failed too (LinAlgError case)  */
-#define VGPA_ST_UNSUPPORTED   4  /* fallback needed but not available on device
-                                    for this D: outputs of this step are NaN    */
+#define VGPA_ST_UNSUPPORTED   4  /* transient mark of a step that waits for the
+                                    fallback pass; never left set when a status
+                                    array was given to the call                 */
 
 /* gradient-assembly flags */
 #define VGPA_GRAD_OUTER 1        /* use outer products lam m', dEsde_db m' instead
@@ -206,6 +207,44 @@ int vgpa_grad_assemble(int P, int N, int D,
                        int edf_system, const double* theta, int theta_stride,
                        const double* SigInv, int sig_stride, double dt, int flags,
                        double* gLA, double* gLb, void* stream);
+
+/*
+ * Sigma points of the unscented transform: the first half of `ut_approx(f, xbar,
+ * Pxx, *args)`, auxiliary/numerical.py:186-208.  k = 1.05 D; rows of
+ * chol((D+k) Pxx)' are added to / subtracted from the mean; when that factorisation
+ * fails the rows of chol(Pxx .* I)' are used instead (:201-202).
+ *   xbar (P,D)  Pxx (P,D,D)  -> chi (P,2D+1,D); status (P) int32 [NULL ok] VGPA_ST_* bits.
+ */
+int vgpa_ut_sigma_points(int P, int D, const double* xbar, const double* Pxx,
+                         double* chi, int* status, void* stream);
+
+/*
+ * Weighted moments of the transformed sigma points: the second half of `ut_approx`,
+ * auxiliary/numerical.py:210-226.  K = 2D+1 fixes the weights (:211-212).
+ *   Y (P,K,C) -> ybar (P,C) = w Y;  Pyy (P,C,C) [NULL ok] = Y' Q Y with
+ *   Q = (I - 1 w') diag(w) (I - 1 w')' exactly as the reference builds it.
+ */
+int vgpa_ut_moments(int P, int K, int C, const double* Y, double* ybar, double* Pyy,
+                    void* stream);
+
+/*
+ * Per-sample gradient terms: replaces core/gradEsde_mS.py:8 `gradEsde_mS(x, F, mt,
+ * St, At, bt, diagSigI, sDyn)`; Fx = F(x, sDyn) is evaluated by the caller.
+ *   x (K,D) Fx (K,D) mt (D) St (D,D) At (D,D) bt (D) dSigI (D)
+ *   -> out (K, D + D*D): row k = [0.5 v_k inv(St) x_k, 0.5 v_k inv(St) z_k z_k' inv(St)].
+ */
+int vgpa_grad_esde_ms(int K, int D, const double* x, const double* Fx, const double* mt,
+                      const double* St, const double* At, const double* bt,
+                      const double* dSigI, double* out, void* stream);
+
+/*
+ * Uncentred moments of a univariate Gaussian and their derivatives: replaces
+ * auxiliary/momGauss.py:5 `momGauss(m, S, order, dmS)`.  order in [0, 8] (anything
+ * else is VGPA_EINVAL, the reference's ValueError :104); deriv 0 = moment, 1 = 'Dm',
+ * 2 = 'DS'.   m (n) S (n) -> out (n).
+ */
+int vgpa_mom_gauss(long long n, const double* m, const double* S, int order, int deriv,
+                   double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -259,11 +259,11 @@ def golden_units(ref, outdir):
         dSigI = 1.0 / (2.0 + rng.random(D))
         f1 = lambda x, At, bt: (drift(x, theta) + x.dot(At.T) - np.tile(bt, (x.shape[0], 1))) ** 2  # noqa
         f2 = lambda x, _: drift(x, theta)  # noqa: E731
-        mbar, _ = num.ut_approx(f1, mt, St, At, bt)
+        mbar, Pyy = num.ut_approx(f1, mt, St, At, bt)
         dmS, _ = num.ut_approx(ref["gradEsde_mS"].gradEsde_mS, mt, St, f2, mt, St, At, bt, dSigI)
         rec.update({f"ut.{tag}.St": St, f"ut.{tag}.mt": mt, f"ut.{tag}.At": At,
                     f"ut.{tag}.bt": bt, f"ut.{tag}.dSigI": dSigI, f"ut.{tag}.theta": np.asarray(theta),
-                    f"ut.{tag}.mbar": mbar, f"ut.{tag}.dmS": dmS})
+                    f"ut.{tag}.mbar": mbar, f"ut.{tag}.Pyy": Pyy, f"ut.{tag}.dmS": dmS})
     np.savez_compressed(os.path.join(outdir, "units.npz"), **rec)
     print("wrote units")
 
@@ -292,6 +292,28 @@ def golden_nonpd_energy(ref, outdir):
     np.savez_compressed(os.path.join(outdir, "l63_ut_nonpd.npz"), **rec)
     print("wrote l63_ut_nonpd")
 
+    # The same for Lorenz-96 at a small and at the benchmark dimension.
+    for D, N, seed in ((6, 12, 31), (40, 6, 32)):
+        rng = np.random.default_rng(300 + D)
+        Ab, m0, S0, sde = build_nd("l96_ut", D, N, seed)
+        A = Ab[:N * D * D].reshape(N, D, D)
+        b = Ab[N * D * D:].reshape(N, D)
+        m = 2.0 * rng.standard_normal((N, D))
+        S = np.zeros((N, D, D))
+        for t in range(N):
+            X = rng.standard_normal((D, D))
+            S[t] = 0.3 * np.eye(D) + 0.1 * X.dot(X.T) / D
+            if t % 3 == 1:
+                S[t] -= 0.6 * np.ones((D, D)) / D
+                S[t][np.diag_indices(D)] = np.abs(S[t][np.diag_indices(D)]) + 0.05
+                assert np.linalg.eigvalsh(S[t]).min() < 0
+        out = ref["l96_ut"].energy_mode(A, b, m, S, sde)
+        rec = _flatten_inputs(Ab, m0, S0, sde)
+        rec.update(m=m, S=S)
+        rec.update({n: np.asarray(v) for n, v in zip(names, out)})
+        np.savez_compressed(os.path.join(outdir, f"l96_ut_nonpd_d{D}.npz"), **rec)
+        print(f"wrote l96_ut_nonpd_d{D}")
+
 
 def golden_scg(ref, outdir):
     """One SCG smoothing run on the Ornstein-Uhlenbeck configuration
@@ -319,6 +341,22 @@ def golden_scg(ref, outdir):
                g_eval=np.int64(stat["g_eval"]), MaxIt=np.int64(stat["MaxIt"]))
     np.savez_compressed(os.path.join(outdir, "scg_ou.npz"), **rec)
     print("wrote scg_ou: fx", fx, "f_eval", stat["f_eval"], "MaxIt", stat["MaxIt"])
+
+    # A short n-D run (analytic Lorenz-63, N=41) from the fixture's own start.
+    D, N = 3, 41
+    Ab, m0, S0, sde = build_nd("l63", D, N, 23)
+    mParam = dict(m0=m0, S0=S0, fun=ref["l63"].energy_mode, sde_struct=sde)
+    nit = 25
+    opts = dict(nit=nit, xtol=1e-6, ftol=1e-8, disp=False, lmin=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x, fx, mParam, stat = ref["optimize"].optim_SCG(
+            ref["varFreeEnergy"].varFreeEnergy, Ab, ref["gradL_Ab"].gradL_Ab, opts, mParam)
+    rec = _flatten_inputs(Ab, m0, S0, sde)
+    rec.update(nit=np.int64(nit), x=x, fx=np.float64(fx), Fx=stat["Fx"], beta=stat["beta"],
+               gradx=stat["gradx"], f_eval=np.int64(stat["f_eval"]),
+               g_eval=np.int64(stat["g_eval"]), MaxIt=np.int64(stat["MaxIt"]))
+    np.savez_compressed(os.path.join(outdir, "scg_l63.npz"), **rec)
+    print("wrote scg_l63: fx", fx, "f_eval", stat["f_eval"], "MaxIt", stat["MaxIt"])
 
 
 def main():

@@ -328,6 +328,19 @@ def ut_sigma_points(m, S):
     return chi.reshape(lead + (2 * D + 1, D)), w, flag.reshape(lead)
 
 
+def ut_approx(f, xbar, Pxx, *args):
+    """auxiliary/numerical.py:153-228 for one mean / covariance: returns
+    (ybar (1,C), Pyy (C,C)).  Q is built exactly as there (:222-223); it is not the
+    usual weighted covariance because the last factor carries the weights a second
+    time."""
+    chi, w, _ = ut_sigma_points(np.asarray(xbar).reshape(-1), np.asarray(Pxx))
+    Y = f(chi, *args)                                       # :216
+    M = w.size
+    wM = np.eye(M) - np.tile(w[None, :], (M, 1))            # :222
+    Q = wM.dot(np.diag(w)).dot(wM.T)                        # :223
+    return w[None, :].dot(Y), Y.T.dot(Q).dot(Y)             # :219, :226
+
+
 def grad_esde_ms(x, Fx, mt, St, At, bt, diagSigI):
     """core/gradEsde_mS.py:8-68, batched: x (...,K,D) samples, Fx (...,K,D) the
     drift at the samples.  Returns (dmt (...,K,D), dSt (...,K,D,D)) per sample."""

@@ -1,0 +1,189 @@
+"""The pieces either side of the hot path, on the device: the stand-alone unscented
+transform, gradEsde_mS, momGauss, mytrapz, the optimisers driving the HIP path, the
+batched finite differences and the module aliases for the reference's drivers."""
+import contextlib
+import io
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr, sde_from_golden, initial_moments
+from oracle import vgpa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+@pytest.mark.parametrize("tag", ["l63", "l96", "l63_npd", "l96_npd"])
+def test_ut_approx_and_grad_esde_ms_vs_golden(tag):
+    from vgpa_amd.auxiliary.numerical import ut_approx
+    from vgpa_amd.core.gradEsde_mS import gradEsde_mS
+    g = load_golden("units.npz")
+    St, mt, At, bt = (g[f"ut.{tag}.{k}"] for k in ("St", "mt", "At", "bt"))
+    dSigI, theta = g[f"ut.{tag}.dSigI"], g[f"ut.{tag}.theta"]
+    D = mt.size
+    drift = (lambda x: orc.lorenz63(x, theta)) if D == 3 else (lambda x: orc.lorenz96(x, float(theta)))
+    f1 = lambda x, At, bt: (drift(x) + x.dot(At.T) - np.tile(bt, (x.shape[0], 1))) ** 2   # noqa: E731
+    f2 = lambda x, _: drift(x)                                                              # noqa: E731
+    mbar, Pyy = ut_approx(f1, mt, St, At, bt)
+    assert mbar.shape == g[f"ut.{tag}.mbar"].shape and Pyy.shape == g[f"ut.{tag}.Pyy"].shape
+    assert relerr(mbar, g[f"ut.{tag}.mbar"]) <= TOL
+    assert relerr(Pyy, g[f"ut.{tag}.Pyy"]) <= TOL
+    # the gradient call of the energy functions: ut_approx over gradEsde_mS
+    dmS, _ = ut_approx(gradEsde_mS, mt, St, f2, mt, St, At, bt, dSigI)
+    assert dmS.shape == g[f"ut.{tag}.dmS"].shape
+    assert relerr(dmS, g[f"ut.{tag}.dmS"]) <= TOL
+    # and gradEsde_mS row by row against the oracle's literal version
+    chi, w, _ = orc.ut_sigma_points(mt, St)
+    rows = gradEsde_mS(chi, f2, mt, St, At, bt, dSigI)
+    dmt, dSt = orc.grad_esde_ms(chi, drift(chi), mt, St, At, bt, dSigI)
+    ref = np.concatenate((dmt, dSt.reshape(chi.shape[0], -1)), axis=1)
+    assert rows.shape == ref.shape and relerr(rows, ref) <= TOL
+
+
+def test_ut_approx_raises_when_no_factorisation_exists():
+    from vgpa_amd.auxiliary.numerical import ut_approx
+    P = np.diag([0.3, -0.2, 0.4])
+    with pytest.raises(np.linalg.LinAlgError):
+        ut_approx(lambda x: x, np.zeros(3), P)
+
+
+def test_mom_gauss_table_vs_golden():
+    from vgpa_amd.auxiliary.momGauss import momGauss
+    g = load_golden("units.npz")
+    m, S = g["mom.m"], g["mom.S"]
+    for order in range(9):
+        for flag in (None, "Dm", "DS"):
+            got = momGauss(m, S, order, flag)
+            want = g[f"mom.{order}.{flag}"]
+            assert got.shape == want.shape, (order, flag)
+            assert relerr(got, want) <= 1e-12, (order, flag)
+    with pytest.raises(ValueError, match="Unknown Higher Order Gaussian Moment"):
+        momGauss(m, S, 9)
+
+
+def test_mytrapz_vs_golden():
+    from vgpa_amd.auxiliary.numerical import mytrapz
+    g = load_golden("units.npz")
+    for col in ("f1", "f3"):
+        f = g[f"trapz.{col}"]
+        got = mytrapz(f, 0.01)
+        assert np.shape(got) == g[f"trapz.{col}.none"].shape and relerr(got, g[f"trapz.{col}.none"]) <= 1e-12
+        for k in ("a", "b", "c"):
+            got = mytrapz(f, 0.01, g[f"trapz.idx.{k}"])
+            assert relerr(got, g[f"trapz.{col}.{k}"]) <= 1e-12, (col, k)
+
+
+def _facade_params(system, g):
+    from vgpa_amd import dynamics   # noqa: F401
+    import importlib
+    mod = dict(ou="sys_ornstein_uhlenbeck", dw="sys_double_well", l63="sys_lorenz_63", l63_ut="sys_lorenz_63_ut",
+               l96_ut="sys_lorenz_96_ut")[system]
+    dyn = importlib.import_module("vgpa_amd.dynamics." + mod)
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    return dict(m0=m0, S0=S0, fun=dyn.energy_mode, sde_struct=sde)
+
+
+@pytest.mark.parametrize("system,fname,rows", [("ou", "scg_ou.npz", 30), ("l63", "scg_l63.npz", 25)])
+def test_optim_scg_through_the_device_replays_the_reference_run(system, fname, rows):
+    """optim_SCG(varFreeEnergy, x0, gradL_Ab, ...) exactly as core/smoothing.py:83 calls
+    it, every evaluation on the GPU.  Rows past ``rows`` of the Ornstein-Uhlenbeck run
+    are below the rounding error of F (the run has stalled) and are not compared."""
+    from vgpa_amd.auxiliary.optimize import optim_SCG
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core.gradL_Ab import gradL_Ab
+    g = load_golden(fname)
+    mParam = _facade_params(system, g)
+    nit = int(g["nit"])
+    x, fx, mParam, stat = _quiet(optim_SCG, varFreeEnergy, g["Ab"], gradL_Ab,
+                                 dict(nit=nit, xtol=1e-6, ftol=1e-8, disp=False, lmin=True), mParam)
+    assert relerr(stat["Fx"][:rows], g["Fx"][:rows]) <= TOL
+    assert relerr(stat["beta"][:rows], g["beta"][:rows]) <= TOL
+    assert relerr(stat["gradx"][:rows], g["gradx"][:rows]) <= 1e-7
+    assert relerr(fx, g["fx"]) <= TOL
+    if rows == nit:
+        assert stat["f_eval"] == int(g["f_eval"]) and stat["g_eval"] == int(g["g_eval"])
+        assert stat["MaxIt"] == int(g["MaxIt"])
+        assert relerr(x, g["x"]) <= 1e-7
+    assert "mt" in mParam and mParam["mt"].shape[0] == int(g["N"])
+
+
+@pytest.mark.parametrize("system,fname,rows", [("ou", "scg_ou.npz", 30), ("l63", "scg_l63.npz", 25)])
+def test_scg_batched_on_device_vs_reference_run(system, fname, rows):
+    """Three copies of the recorded problem, the middle one with other observations:
+    copies 0 and 2 must reproduce the recorded run, whatever copy 1 does."""
+    import torch
+    from vgpa_amd import engine, _lib
+    from vgpa_amd.auxiliary.optimize import scg_batched
+    g = load_golden(fname)
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    N, D, P = int(g["N"]), int(g["D"]), 3
+    obsY = np.array(sde["obsY"], dtype=np.float64).reshape(len(sde["obsX"]), -1)
+    sde["obsY"] = np.stack([obsY, 0.5 * obsY + 0.2, obsY])
+    prob = engine.make_problem(_lib.SYSTEMS[system], sde, m0, S0, P=P)
+    A0, b0 = orc.unpack_Ab(g["Ab"], N, D)
+    shpA, shpb = ((P, N), (P, N)) if D == 1 else ((P, N, D, D), (P, N, D))
+    A = engine.to_dev(np.broadcast_to(A0.reshape(shpA[1:]), shpA))
+    b = engine.to_dev(np.broadcast_to(b0.reshape(shpb[1:]), shpb))
+    nit = int(g["nit"])
+    Aout, bout, F, stat = scg_batched(prob, A, b, nit=nit)
+    Fx, beta = stat["Fx"].cpu().numpy(), stat["beta"].cpu().numpy()
+    for p in (0, 2):
+        assert relerr(Fx[:rows, p], g["Fx"].ravel()[:rows]) <= TOL
+        assert relerr(beta[:rows, p], g["beta"].ravel()[:rows]) <= TOL
+        assert relerr(F[p].item(), g["fx"]) <= TOL
+        if rows == nit:
+            assert int(stat["f_eval"][p]) == int(g["f_eval"]) and int(stat["MaxIt"][p]) == int(g["MaxIt"])
+            xp = np.concatenate((Aout[p].reshape(-1).cpu().numpy(), bout[p].reshape(-1).cpu().numpy()))
+            assert relerr(xp, g["x"].ravel()) <= 1e-7
+    assert relerr(Fx[:rows, 1], g["Fx"].ravel()[:rows]) > 1e-3
+    assert torch.equal(stat["Fx"][:, 0], stat["Fx"][:, 2])   # identical problems, identical arithmetic
+
+
+def test_finite_differences_batched_equal_one_by_one():
+    from vgpa_amd.auxiliary.numerical import finiteDiff
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    g = load_golden("sys_l63.npz")
+    mParam = _facade_params("l63", g)
+    x = np.array(g["Ab"], dtype=np.float64).reshape(-1, 1)
+    got = _quiet(finiteDiff, varFreeEnergy, x, mParam)
+    assert got.shape == x.shape
+    rng = np.random.default_rng(0)
+    h = 1e-6
+    for i in rng.choice(x.size, 12, replace=False):
+        e = np.zeros_like(x)
+        e[i] = h
+        want = 0.5 * (varFreeEnergy(x + e, dict(mParam)) - varFreeEnergy(x - e, dict(mParam))) / h
+        assert abs(got[i, 0] - want) <= 1e-6 * max(1.0, abs(want))
+
+
+def test_compat_aliases_bind_the_reference_module_names():
+    import vgpa_amd.compat as compat
+    import vgpa_amd.core.varFreeEnergy as ours
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("core", "dynamics", "auxiliary")}
+    try:
+        names = compat.install()
+        assert "core.varFreeEnergy" in names and "dynamics.sys_lorenz_96_ut" in names
+        from core.varFreeEnergy import varFreeEnergy          # the import lines of core/smoothing.py:5-10
+        from core.gradL_Ab import gradL_Ab                     # noqa: F401
+        from auxiliary.optimize import optim_SCG               # noqa: F401
+        from dynamics import sys_lorenz_63 as dyn
+        assert varFreeEnergy is ours.varFreeEnergy
+        g = load_golden("sys_l63.npz")
+        mParam = dict(m0=initial_moments(g)[0], S0=initial_moments(g)[1], fun=dyn.energy_mode,
+                      sde_struct=sde_from_golden(g))
+        assert abs(varFreeEnergy(g["Ab"], mParam) - float(g["EULER.F"])) <= TOL * abs(float(g["EULER.F"]))
+    finally:
+        compat.uninstall()
+        for k in [k for k in sys.modules if k.split(".")[0] in ("core", "dynamics", "auxiliary")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -152,17 +152,37 @@ def test_lorenz63_unscented_cholesky_fallback_vs_golden():
         assert relerr(v, g[n]) <= TOL, n
 
 
-def test_lorenz96_non_positive_definite_covariance_is_reported():
+@pytest.mark.parametrize("fname", ["l96_ut_nonpd_d6.npz", "l96_ut_nonpd_d40.npz"])
+def test_lorenz96_unscented_cholesky_fallback_vs_golden(fname):
+    """Every third S(t) has a negative eigenvalue: those steps take the diagonal
+    sigma points of auxiliary/numerical.py:201-202 (D=6: generic kernel; D=40: the
+    tiled kernel flags the step and the fallback pass redoes it)."""
     from vgpa_amd.dynamics import sys_lorenz_96_ut
-    g = load_golden("units.npz")
-    St, mt, At, bt = (g[f"ut.l96_npd.{k}"] for k in ("St", "mt", "At", "bt"))
-    D = mt.size
+    g = load_golden(fname)
+    sde = sde_from_golden(g)
+    A, b = orc.unpack_Ab(g["Ab"], sde["N"], sde["D"])
+    out = sys_lorenz_96_ut.energy_mode(A, b, g["m"], g["S"], sde)
+    names = ["Esde", "Ef", "Edf", "dEsde_dm", "dEsde_dS", "dEsde_dth", "dEsde_dSig"]
+    for n, v in zip(names, out):
+        assert np.asarray(v).shape == g[n].shape, n
+        assert relerr(v, g[n]) <= TOL, n
+
+
+@pytest.mark.parametrize("D", [6, 40])
+def test_lorenz96_covariance_without_any_cholesky_raises_like_numpy(D):
+    """A non-positive diagonal entry defeats the diagonal fallback too; the reference
+    lets numpy's LinAlgError escape (auxiliary/numerical.py:202)."""
+    from vgpa_amd.dynamics import sys_lorenz_96_ut
+    rng = np.random.default_rng(D)
+    St = 0.3 * np.eye(D)
+    St[2, 2] = -0.1
     sde = dict(N=1, D=D, dt=0.01, Sig=np.eye(D), theta=8.0, obsX=np.array([0]))
     with pytest.raises(np.linalg.LinAlgError):
-        sys_lorenz_96_ut.energy_mode(At[None], bt[None], mt[None], St[None], sde)
+        sys_lorenz_96_ut.energy_mode(8.0 * np.eye(D)[None], rng.standard_normal((1, D)),
+                                     rng.standard_normal((1, D)), St[None], sde)
 
 
-@pytest.mark.parametrize("tag,system", [("l63", "l63_ut"), ("l96", "l96_ut")])
+@pytest.mark.parametrize("tag,system", [("l63", "l63_ut"), ("l96", "l96_ut"), ("l63_npd", "l63_ut"), ("l96_npd", "l96_ut")])
 def test_unscented_single_step_vs_golden(tag, system):
     """The closed-form sigma-point reduction of the kernels against the
     per-sigma-point vectors ut_approx / gradEsde_mS produced in the reference."""

@@ -87,18 +87,26 @@ def test_unscented_single_step(tag):
     dmt, dSt = orc.grad_esde_ms(chi, Fx, mt, St, At, bt, dSigI)
     dmS = np.concatenate((w.dot(dmt), np.einsum("k,kij->ij", w, dSt).ravel()))
     assert relerr(dmS, g[f"ut.{tag}.dmS"]) <= 1e-11
+    # the complete ut_approx, second output included
+    f1 = lambda x, At, bt: (drift(x) + x.dot(At.T) - bt) ** 2   # noqa: E731
+    ybar, Pyy = orc.ut_approx(f1, mt, St, At, bt)
+    assert ybar.shape == g[f"ut.{tag}.mbar"].shape and Pyy.shape == g[f"ut.{tag}.Pyy"].shape
+    assert relerr(ybar, g[f"ut.{tag}.mbar"]) <= TOL
+    assert relerr(Pyy, g[f"ut.{tag}.Pyy"]) <= 1e-11
 
 
-def test_energy_mode_nonpd_fallback():
-    g = load_golden("l63_ut_nonpd.npz")
+@pytest.mark.parametrize("system,fname", [("l63_ut", "l63_ut_nonpd.npz"), ("l96_ut", "l96_ut_nonpd_d6.npz"),
+                                          ("l96_ut", "l96_ut_nonpd_d40.npz")])
+def test_energy_mode_nonpd_fallback(system, fname):
+    g = load_golden(fname)
     sde = sde_from_golden(g)
     N, D = sde["N"], sde["D"]
     A, b = orc.unpack_Ab(g["Ab"], N, D)
-    out = orc.energy_mode("l63_ut", A, b, g["m"], g["S"], sde)
+    out = orc.energy_mode(system, A, b, g["m"], g["S"], sde)
     names = ["Esde", "Ef", "Edf", "dEsde_dm", "dEsde_dS", "dEsde_dth", "dEsde_dSig"]
     for n, v in zip(names, out[:7]):
         assert relerr(v, g[n]) <= 1e-11, n
-    assert out[7]["flag"].sum() == 4
+    assert out[7]["flag"].sum() == len(range(1, N, 3))
 
 
 def test_unknown_method_raises():

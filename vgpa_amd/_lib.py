@@ -50,6 +50,10 @@ SIGNATURES = {
     "vgpa_kl0": [_c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _ptr],
     "vgpa_grad_assemble": [_c_int, _c_int, _c_int] + [_ptr] * 8 + [_c_int, _ptr, _c_int, _ptr, _c_int, _c_dbl, _c_int,
                            _ptr, _ptr, _ptr],
+    "vgpa_ut_sigma_points": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "vgpa_ut_moments": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "vgpa_grad_esde_ms": [_c_int, _c_int] + [_ptr] * 8 + [_ptr],
+    "vgpa_mom_gauss": [ctypes.c_longlong, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
 }
 EXPORTS = ["vgpa_version", "vgpa_last_error_string"] + list(SIGNATURES)
 
@@ -88,4 +92,6 @@ def call(name, *args):
         msg = lib.vgpa_last_error_string().decode("utf-8", "replace")
         if "Unknown method of integration" in msg:
             raise ValueError("Unknown method of integration")
+        if "Unknown Higher Order Gaussian Moment" in msg:
+            raise ValueError("Unknown Higher Order Gaussian Moment!")
         raise VgpaError(f"{name} failed ({rc}): {msg}")

@@ -4,7 +4,7 @@ import numpy as np
 from .. import engine
 from . import _facade
 
-__all__ = ["varFreeEnergy"]
+__all__ = ["varFreeEnergy", "finite_difference_batched"]
 
 
 def _evaluate(Ab, mParam, want_hyper=False):
@@ -44,3 +44,45 @@ def varFreeEnergy(Ab, mParam):
     prob, _, _, st = _evaluate(Ab, mParam)
     _publish(mParam, st, prob.D)
     return float(st.F[0].item())
+
+
+def finite_difference_batched(x, mParam, h=1.0e-6, max_bytes=1 << 28):
+    """Central differences of F along every coordinate of ``x`` (the work of
+    auxiliary/numerical.py:132-144) with the 2n perturbed points evaluated as device
+    batches: each batch holds k coordinates, rows 0..k-1 at x + h e_i and rows k..2k-1
+    at x - h e_i.  Returns the (n,1) column of the reference."""
+    import torch
+    sde = mParam["sde_struct"]
+    N, D = int(sde["N"]), int(sde["D"])
+    fun = mParam["fun"]
+    system = _facade.system_of(fun)
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    n = x.size
+    if system < 0:
+        # a host plug-in gains nothing from batching: one point at a time
+        grad = np.zeros((n, 1))
+        e = np.zeros(n)
+        for i in range(n):
+            e[i] = h
+            grad[i] = 0.5 * (varFreeEnergy(x + e, dict(mParam)) - varFreeEnergy(x - e, dict(mParam))) / h
+            e[i] = 0.0
+        return grad
+    nA = N * D * D
+    per = max(1, min(n, int(max_bytes // (16 * n))))
+    base = engine.to_dev(x)
+    grad = torch.empty(n, dtype=torch.float64, device=base.device)
+    shape_A = (N,) if D == 1 else (N, D, D)
+    shape_b = (N,) if D == 1 else (N, D)
+    for start in range(0, n, per):
+        k = min(per, n - start)
+        X = base.repeat(2 * k, 1)
+        rows = torch.arange(k, device=base.device)
+        X[rows, start + rows] += h
+        X[k + rows, start + rows] -= h
+        A = X[:, :nA].reshape((2 * k,) + shape_A).contiguous()
+        b = X[:, nA:].reshape((2 * k,) + shape_b).contiguous()
+        prob = engine.make_problem(system, sde, mParam["m0"], mParam["S0"], P=2 * k)
+        st = engine.free_energy(prob, A, b, want_edf=False, need_adjoint=False)
+        engine.check_status(st.status)
+        grad[start:start + k] = 0.5 * (st.F[:k] - st.F[k:]) / h
+    return grad.cpu().numpy().reshape(n, 1)

@@ -1,6 +1,7 @@
 // Time reductions, observation terms, initial-state KL energy and the assembly of
 // dL/dA, dL/db, gfx950.
 #include "common.h"
+#include "linalg.h"
 
 #include <cmath>
 
@@ -130,52 +131,10 @@ __global__ void obs_terms_1d_kernel(int P, int N, int M, const double* __restric
     if (p == 0 && jumpS) jumpS[0] = 0.5 * Ri;
 }
 
+
 // ---------------------------------------------------------------------------
 // KL0, D > 1: one wavefront per problem, matrices in LDS.  core/kl0.py:72-99.
 // ---------------------------------------------------------------------------
-// In-place Gauss-Jordan inverse with partial pivoting of the D x D matrix M
-// (row stride LD) using the D x D scratch I (same stride); result in I.
-__device__ void gj_inverse(double* M, double* I, int D, int LD, int l) {
-    for (int q = l; q < D * D; q += 64) I[(q / D) * LD + (q % D)] = (q / D == q % D) ? 1.0 : 0.0;
-    __syncthreads();
-    for (int k = 0; k < D; ++k) {
-        // pivot search over rows k..D-1 of column k
-        double best = -1.0;
-        int brow = k;
-        for (int r = k + l; r < D; r += 64) {
-            const double v = fabs(M[r * LD + k]);
-            if (v > best) { best = v; brow = r; }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ob = __shfl_xor(best, off, 64);
-            const int orow = __shfl_xor(brow, off, 64);
-            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-        }
-        if (brow != k) {
-            for (int j = l; j < D; j += 64) {
-                double t = M[k * LD + j]; M[k * LD + j] = M[brow * LD + j]; M[brow * LD + j] = t;
-                t = I[k * LD + j]; I[k * LD + j] = I[brow * LD + j]; I[brow * LD + j] = t;
-            }
-        }
-        __syncthreads();
-        const double rp = 1.0 / M[k * LD + k];
-        __syncthreads();
-        for (int j = l; j < D; j += 64) { M[k * LD + j] *= rp; I[k * LD + j] *= rp; }
-        __syncthreads();
-        for (int r = 0; r < D; ++r) {
-            if (r == k) continue;
-            const double f = M[r * LD + k];
-            __syncthreads();
-            for (int j = l; j < D; j += 64) {
-                M[r * LD + j] = fma(-f, M[k * LD + j], M[r * LD + j]);
-                I[r * LD + j] = fma(-f, I[k * LD + j], I[r * LD + j]);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 __global__ void __launch_bounds__(64)
 kl0_nd_kernel(int D, const double* __restrict__ m0, const double* __restrict__ S0,
               const double* __restrict__ mu0, int mu0_stride, const double* __restrict__ tau0, int tau0_stride,
@@ -194,10 +153,10 @@ kl0_nd_kernel(int D, const double* __restrict__ m0, const double* __restrict__ S
     for (int q = l; q < (int)DD; q += 64) Ma[(q / D) * LD + (q % D)] = S0p[q];
     if (l < D) z[l] = m0[(size_t)p * D + l] - mu0[(size_t)p * mu0_stride + l];
     __syncthreads();
-    gj_inverse(Ma, S0i, D, LD, l);
+    vgpa::gj_inverse(Ma, S0i, D, LD, l);
     for (int q = l; q < (int)DD; q += 64) Ma[(q / D) * LD + (q % D)] = t0p[q];
     __syncthreads();
-    gj_inverse(Ma, T0i, D, LD, l);
+    vgpa::gj_inverse(Ma, T0i, D, LD, l);
     // Pm = tau0 * S0i
     for (int q = l; q < (int)DD; q += 64) {
         const int i = q / D, j = q % D;

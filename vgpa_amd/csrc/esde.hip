@@ -16,6 +16,7 @@
 // dynamics/sys_lorenz_96_ut.py:238-241 evaluate to (the centre point has z = 0 and
 // the Esde m terms cancel exactly).
 #include "common.h"
+#include "linalg.h"
 
 #include <cmath>
 
@@ -393,6 +394,149 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------
+// Lorenz-96, one step whose S(t) is not positive definite.  The reference then
+// takes sigma points from the square roots of the diagonal alone, unscaled
+// (auxiliary/numerical.py:201-202), and its gradient code solves with the full
+// S(t) (core/gradEsde_mS.py:48-60).  With z_i = +/- s_i e_i, s_i = sqrt(S_ii), and
+// Si = inv(S) that gives
+//   dEsde/dm = (w/2) Si (s .* (v+ - v-))
+//   dEsde/dS = (w/4) Si diag(S_ii (v+ + v-)) Si - (Esde_t/2) Si .
+// One wavefront; Ef / Edf / the theta integrand have been written by the caller.
+// LDS: 3 D (D+1) + 5 D doubles.
+// ---------------------------------------------------------------------------
+__device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
+    const int D = a.D, LD = D + 1, MS = D * LD;
+    const int l = threadIdx.x;
+    const int p = (int)(e / a.N);
+    const size_t DD = (size_t)D * D;
+    double* Sm = lds;
+    double* Si = lds + MS;
+    double* Am = lds + 2 * MS;
+    double* mv = lds + 3 * MS;
+    double* bv = mv + D;
+    double* sv = bv + D;
+    double* uv = sv + D;
+    double* gv = uv + D;
+    __syncthreads();
+    const double theta = a.theta[(size_t)p * a.theta_stride];
+    const double* Ag = a.A + e * DD;
+    const double* Sg = a.S + e * DD;
+    for (int q = l; q < (int)DD; q += 64) {
+        const int o = (q / D) * LD + (q % D);
+        Am[o] = Ag[q];
+        Sm[o] = Sg[q];
+    }
+    const bool act = l < D;
+    double sI = 0.0, m_l = 0.0, sdiag = 1.0;
+    if (act) {
+        m_l = a.m[e * D + l];
+        mv[l] = m_l;
+        bv[l] = a.b[e * D + l];
+        sI = a.sig_inv_diag[(size_t)p * a.sig_stride + l];
+        sdiag = Sg[(size_t)l * D + l];
+    }
+    const double nan = __builtin_nan("");
+    if (!__all(sdiag > 0.0)) {
+        // the diagonal has no Cholesky factor either: numpy raises LinAlgError here
+        if (l == 0) {
+            a.Esde_t[e] = nan;
+            if (a.status) a.status[e] = VGPA_ST_CHOL_FALLBACK | VGPA_ST_CHOL_FAILED;
+        }
+        if (act) {
+            a.dEdm[e * D + l] = nan;
+            if (a.dSig_t) a.dSig_t[e * D + l] = nan;
+        }
+        for (int q = l; q < (int)DD; q += 64) a.dEdS[e * DD + q] = nan;
+        return;
+    }
+    if (act) sv[l] = sqrt(sdiag);
+    __syncthreads();
+
+    const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + 2 * D - 2) % D;
+    double base = 0.0;
+    if (act) {
+        double am = 0.0;
+        for (int k = 0; k < D; ++k) am = fma(Am[l * LD + k], mv[k], am);
+        base = am - bv[l];
+    }
+    const double kappa = 1.05 * D;
+    const double c2 = D + kappa;
+    const double w0 = kappa / c2, w1 = 1.0 / (2.0 * c2);
+    double mbar = 0.0, a0 = 0.0;
+    if (act) {
+        const double f0 = (mv[f1] - mv[b2]) * mv[b1] - m_l + theta;
+        const double r0 = f0 + base;
+        mbar = w0 * r0 * r0;
+        a0 = sI * r0 * r0;
+    }
+    const double v0 = wave_sum(a0);
+    double vsum = 0.0, u_l = 0.0, g_l = 0.0;
+    for (int i = 0; i < D; ++i) {
+        const double si = sv[i];
+        double ap = 0.0, am = 0.0;
+        if (act) {
+            const double sa = si * Am[l * LD + i];
+            const double o0 = (l == i) ? si : 0.0, of1 = (f1 == i) ? si : 0.0;
+            const double ob1 = (b1 == i) ? si : 0.0, ob2 = (b2 == i) ? si : 0.0;
+            const double xf1 = mv[f1], xb1 = mv[b1], xb2 = mv[b2];
+            const double fp = ((xf1 + of1) - (xb2 + ob2)) * (xb1 + ob1) - (m_l + o0) + theta;
+            const double fm = ((xf1 - of1) - (xb2 - ob2)) * (xb1 - ob1) - (m_l - o0) + theta;
+            const double rp = fp + base + sa;
+            const double rm = fm + base - sa;
+            mbar += w1 * (rp * rp + rm * rm);
+            ap = sI * rp * rp;
+            am = sI * rm * rm;
+        }
+        const double vp = wave_sum(ap), vm = wave_sum(am);
+        vsum += vp + vm;
+        if (l == i) {
+            u_l = si * (vp - vm);
+            g_l = si * si * (vp + vm);
+        }
+    }
+    const double Esde = 0.5 * (w0 * v0 + w1 * vsum);
+    if (l == 0) {
+        a.Esde_t[e] = Esde;
+        if (a.status) a.status[e] = VGPA_ST_CHOL_FALLBACK;
+    }
+    if (act) {
+        if (a.dSig_t) a.dSig_t[e * D + l] = mbar;
+        uv[l] = u_l;
+        gv[l] = g_l;
+    }
+    __syncthreads();
+    vgpa::gj_inverse(Sm, Si, D, LD, l);
+    if (act) {
+        double y = 0.0;
+        for (int j = 0; j < D; ++j) y = fma(Si[l * LD + j], uv[j], y);
+        a.dEdm[e * D + l] = 0.5 * w1 * y;
+    }
+    double* G = a.dEdS + e * DD;
+    for (int i = 0; i < D; ++i) {
+        if (act) {
+            double s = 0.0;
+            for (int k = 0; k < D; ++k) s = fma(Si[i * LD + k] * gv[k], Si[k * LD + l], s);
+            G[i * D + l] = 0.25 * w1 * s - 0.5 * Esde * Si[i * LD + l];
+        }
+    }
+}
+
+// After a kernel that only flags such steps: every wavefront looks at 64
+// consecutive steps and redoes the flagged ones.
+__global__ void __launch_bounds__(64) esde_l96_fixup_kernel(EsdeArgs a, size_t total) {
+    extern __shared__ double lds[];
+    const size_t e0 = (size_t)blockIdx.x * 64;
+    const size_t mine = e0 + threadIdx.x;
+    const int st = (mine < total) ? a.status[mine] : 0;
+    unsigned long long todo = __ballot((st & VGPA_ST_UNSUPPORTED) != 0);
+    while (todo) {
+        const int i = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        l96_fallback_step(a, e0 + i, lds);
+    }
+}
+
 __global__ void __launch_bounds__(64) esde_l96_ut_kernel(EsdeArgs a) {
     extern __shared__ double lds[];
     const int D = a.D, LD = D + 1, MS = D * LD;
@@ -476,18 +620,7 @@ __global__ void __launch_bounds__(64) esde_l96_ut_kernel(EsdeArgs a) {
         __syncthreads();
     }
     if (!ok) {
-        // The diagonal fallback needs a general inverse of S, which this kernel
-        // does not implement: flag the step and poison its energy outputs.
-        const double nan = __builtin_nan("");
-        if (l == 0) {
-            a.Esde_t[e] = nan;
-            if (a.status) a.status[e] = VGPA_ST_CHOL_FALLBACK | VGPA_ST_UNSUPPORTED;
-        }
-        if (act) {
-            a.dEdm[e * D + l] = nan;
-            if (a.dSig_t) a.dSig_t[e * D + l] = nan;
-        }
-        for (int q = l; q < (int)DD; q += 64) a.dEdS[e * DD + q] = nan;
+        l96_fallback_step(a, e, lds);
         return;
     }
     // Zero the strict upper triangle so that column reads need no masking.
@@ -601,6 +734,13 @@ template <int D>
 void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
     if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
     else launch_l96_tiled_h<D, false>(a, total, st);
+    if (a.status) {
+        // steps the tiled kernel flagged as not positive definite
+        const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 5 * D);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_fixup_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(esde_l96_fixup_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), lds, st, a, total);
+    }
 }
 
 int launch_esde(int system, const EsdeArgs& a, hipStream_t st) {

@@ -266,7 +266,8 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
     }
     if (sc[0] != 0.0) {
         // Not positive definite.  The reference falls back to diagonal sigma points,
-        // which needs a general inverse of S: flag the step and poison its outputs.
+        // which needs a general inverse of S: flag the step for the fallback pass that
+        // follows this kernel and poison its outputs in case there is none.
         const double nan = __builtin_nan("");
         if (tid == 0) {
             a.Esde_t[e] = nan;

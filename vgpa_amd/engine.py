@@ -343,6 +343,39 @@ def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False):
     return gLA, gLb
 
 
+def ut_sigma_points(xbar, Pxx):
+    """vgpa_ut_sigma_points: xbar (P,D), Pxx (P,D,D) -> chi (P,2D+1,D), status (P,)."""
+    P, D = xbar.shape
+    chi = torch.empty((P, 2 * D + 1, D), dtype=F64, device=xbar.device)
+    status = torch.zeros((P,), dtype=torch.int32, device=xbar.device)
+    call("vgpa_ut_sigma_points", P, D, _p(xbar), _p(Pxx), _p(chi), _p(status), _stream())
+    return chi, status
+
+
+def ut_moments(Y, want_cov=True):
+    """vgpa_ut_moments: Y (P,K,C) -> ybar (P,C), Pyy (P,C,C) or None."""
+    P, K, C = Y.shape
+    ybar = torch.empty((P, C), dtype=F64, device=Y.device)
+    Pyy = torch.empty((P, C, C), dtype=F64, device=Y.device) if want_cov else None
+    call("vgpa_ut_moments", P, K, C, _p(Y), _p(ybar), _p(Pyy), _stream())
+    return ybar, Pyy
+
+
+def grad_esde_ms(x, Fx, mt, St, At, bt, dSigI):
+    """vgpa_grad_esde_ms: x, Fx (K,D) -> (K, D + D*D)."""
+    K, D = x.shape
+    out = torch.empty((K, D * (D + 1)), dtype=F64, device=x.device)
+    call("vgpa_grad_esde_ms", K, D, _p(x), _p(Fx), _p(mt), _p(St), _p(At), _p(bt), _p(dSigI), _p(out), _stream())
+    return out
+
+
+def mom_gauss(m, S, order, deriv):
+    """vgpa_mom_gauss on flat device tensors."""
+    out = torch.empty_like(m)
+    call("vgpa_mom_gauss", m.numel(), _p(m), _p(S), int(order), int(deriv), _p(out), _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------
 # the evaluation
 # ---------------------------------------------------------------------------
@@ -395,8 +428,8 @@ class State:
     Esde: torch.Tensor
     m: torch.Tensor
     S: torch.Tensor
-    lam: torch.Tensor
-    Psi: torch.Tensor
+    lam: Optional[torch.Tensor]
+    Psi: Optional[torch.Tensor]
     Ef: torch.Tensor
     Edf: torch.Tensor
     dEdm: torch.Tensor
@@ -408,10 +441,11 @@ class State:
     dSig: Optional[torch.Tensor] = None
 
 
-def free_energy(prob, A, b, want_hyper=False, want_edf=True):
+def free_energy(prob, A, b, want_hyper=False, want_edf=True, need_adjoint=True):
     """core/varFreeEnergy.py:80-111 for a batch: returns a State with F (P,).
     ``want_edf=False`` (Lorenz systems) skips the dense <df/dx> array; ``gradient``
-    then lets the assembly kernel derive it from the mean."""
+    then lets the assembly kernel derive it from the mean.  ``need_adjoint=False``
+    skips the backward scan (lam, Psi are None): enough when only F is wanted."""
     m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
     Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
     if prob.system < 0:
@@ -420,8 +454,10 @@ def free_energy(prob, A, b, want_hyper=False, want_edf=True):
         en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w,
                           prob.dt, want_hyper, want_edf=want_edf or prob.D == 1)
     sym = prob.sym_jump and prob.system >= 0 and esde_output_is_symmetric(prob.system, prob.D)
-    lam, Psi = bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-                        obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym)
+    lam = Psi = None
+    if need_adjoint:
+        lam, Psi = bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
+                            obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym)
     KL0 = kl0(prob)
     F = KL0 + Eobs + en["Esde"]
     return State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"],
