@@ -68,8 +68,9 @@ def test_time_windows_on_device_vs_golden(name, world, method):
     assert relerr(grad, g[f"{method}.grad"].reshape(-1)) <= TOL
     m = torch.cat([out[r][0].m for r in range(world)], dim=1).cpu().numpy()
     lam = torch.cat([out[r][0].lam for r in range(world)], dim=1).cpu().numpy()
-    assert relerr(m.reshape(-1), g[f"{method}.m"].reshape(-1)) <= TOL
-    assert relerr(lam.reshape(-1), g[f"{method}.lam"].reshape(-1)) <= TOL
+    if f"{method}.m" in g:   # the large fixture keeps intermediates for one method only
+        assert relerr(m.reshape(-1), g[f"{method}.m"].reshape(-1)) <= TOL
+        assert relerr(lam.reshape(-1), g[f"{method}.lam"].reshape(-1)) <= TOL
 
 
 def test_time_windows_batched_microbatches_match_unsharded_device():

@@ -86,8 +86,11 @@ __global__ void ut_mean_kernel(int P, int K, int C, const double* __restrict__ Y
     ybar[idx] = s;
 }
 
-// Pyy = Y' Q Y with Q = (I - 1 w') diag(w) (I - 1 w')'  (numerical.py:222-226), i.e.
-// Q = diag(w) - 2 w w' + (sum_k w_k^3) 1 1'.  16 x 16 outputs per block.
+// Pyy = Y' Q Y with Q = (I - 1 w') diag(w) (I - 1 w')'  (numerical.py:222-226).
+// Entry (i,l) of Q is  delta_il w_i - w_i^2 - w_l^2 + sum_k w_k^3,  so with
+// q = sum_k w_k^2 y_k and t = sum_k y_k:
+//   Pyy = sum_k w_k y_k y_k' - q t' - t q' + (sum_k w_k^3) t t'.
+// 16 x 16 outputs per block.
 __global__ void __launch_bounds__(256)
 ut_cov_kernel(int K, int C, const double* __restrict__ Y, double w0, double w1, double w3,
               double* __restrict__ Pyy) {
@@ -95,17 +98,17 @@ ut_cov_kernel(int K, int C, const double* __restrict__ Y, double w0, double w1, 
     const int a = blockIdx.y * 16 + threadIdx.y, c = blockIdx.x * 16 + threadIdx.x;
     if (a >= C || c >= C) return;
     const double* y = Y + (size_t)p * K * C;
-    double saa = 0.0, ma = 0.0, mc = 0.0, ta = 0.0, tc = 0.0;
+    double sac = 0.0, qa = 0.0, qc = 0.0, ta = 0.0, tc = 0.0;
     for (int k = 0; k < K; ++k) {
         const double w = k == 0 ? w0 : w1;
         const double ya = y[(size_t)k * C + a], yc = y[(size_t)k * C + c];
-        saa = fma(w * ya, yc, saa);
-        ma = fma(w, ya, ma);
-        mc = fma(w, yc, mc);
+        sac = fma(w * ya, yc, sac);
+        qa = fma(w * w, ya, qa);
+        qc = fma(w * w, yc, qc);
         ta += ya;
         tc += yc;
     }
-    Pyy[(size_t)p * C * C + (size_t)a * C + c] = saa - 2.0 * ma * mc + w3 * ta * tc;
+    Pyy[(size_t)p * C * C + (size_t)a * C + c] = sac - qa * tc - ta * qc + w3 * ta * tc;
 }
 
 // One wavefront per sample k.  LDS: 2 D (D+1) + 4 D doubles.
