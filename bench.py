@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--problems", type=int, default=128, help="problems per GPU")
+    ap.add_argument("--problems", type=int, default=256, help="problems per GPU")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
