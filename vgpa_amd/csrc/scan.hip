@@ -874,9 +874,18 @@ void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+#include "scan_mfma.h"
+
 template <int METHOD, int DT, bool SYM>
 void launch_fwd(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                 const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
+    if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
+        const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
+        allow_lds(fwd_euler_sym_mfma40_kernel, lds);
+        hipLaunchKernelGGL(fwd_euler_sym_mfma40_kernel, dim3(P), dim3(M40::NT), lds, st, N, A, b, m0, S0, Sigma,
+                           sigma_stride, dt, m_out, S_out);
+        return;
+    }
     const size_t lds = nd_lds_bytes(D, DT > 0, METHOD, SYM);
     allow_lds(fwd_scan_nd_kernel<METHOD, DT, SYM>, lds);
     hipLaunchKernelGGL((fwd_scan_nd_kernel<METHOD, DT, SYM>), dim3(P), dim3(nd_threads(D, DT > 0)), lds, st, N, D, A, b, m0,
@@ -887,6 +896,15 @@ template <int METHOD, int DT, bool SYM>
 void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                 const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                 const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
+    if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
+        if (!jS) {
+            const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
+            allow_lds(bwd_euler_sym_mfma40_kernel, lds);
+            hipLaunchKernelGGL(bwd_euler_sym_mfma40_kernel, dim3(P), dim3(M40::NT), lds, st, N, A, dEdm, dEdS, jm,
+                               obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+            return;
+        }
+    }
     const size_t lds = nd_lds_bytes(D, DT > 0, METHOD, SYM);
     allow_lds(bwd_scan_nd_kernel<METHOD, DT, SYM>, lds);
     hipLaunchKernelGGL((bwd_scan_nd_kernel<METHOD, DT, SYM>), dim3(P), dim3(nd_threads(D, DT > 0)), lds, st, N, D, A, dEdm,
@@ -966,3 +984,9 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
     }
     return vgpa::check_launch("vgpa_bwd_scan");
 }
+
+#ifdef VGPA_STAMPS
+extern "C" int vgpa_debug_m40_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_m40_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1,0 +1,344 @@
+// Euler scans at D = 40 with symmetric state on the FP64 matrix cores.
+//
+// The one matrix product of a step (A S forward, Psi A backward; the other half of
+// the right-hand side is its transpose because the state is symmetric) is done with
+// v_mfma_f64_16x16x4_f64 on 16 x 16 tiles of the 40 x 40 result padded to 48 x 48:
+// wavefront r (r = 0, 1, 2) owns the three tiles of tile row r, the fourth wavefront
+// integrates the vector state (m or lam).  Compared with register tiles on the
+// vector ALU this cuts LDS reads per step from about 380 KB to about 60 KB, which is
+// what bounds the vector-ALU kernels once two workgroups share a CU.
+//
+// Operand layout (one f64 per lane and instruction): lane l supplies A[l & 15][l >> 4]
+// and B[l >> 4][l & 15]; the result registers hold C[(l >> 4) + 4 reg][l & 15].  Which
+// k a lane group contributes is free as long as both operands agree, so group g takes
+// k = 10 g .. 10 g + 9: both operands are then read as rows, ten contiguous doubles
+// per lane (16-byte LDS reads).  Both products are "row times row":
+//   forward   (A S)[i][j]   = sum_k A[i][k] S[j][k]     (S symmetric)
+//   backward  (Psi A)[i][j] = sum_k Psi[i][k] At[j][k]  (At = A' staged transposed)
+// Tile rows / columns 40..47 do not exist: their operand rows are clamped to row 39
+// and the results are never stored.
+//
+// Included by scan.hip inside its anonymous namespace.
+
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+
+#ifdef VGPA_STAMPS
+__device__ unsigned long long g_m40_stamps[64];
+#define M40_STAMP(k) do { if (blockIdx.x == 7 && t == 1000 && lane == 0) g_m40_stamps[wid * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define M40_STAMP(k) do { } while (0)
+#endif
+
+struct M40 {
+    static constexpr int D = 40, LD = 42, MS = D * LD, DD = D * D;
+    static constexpr int NT = 256;      // three matrix wavefronts + one vector wavefront
+    static constexpr int NSTAGE = 200;  // threads that stage A: 200 x 4 x 16 bytes = one matrix
+    static constexpr int LDS_DOUBLES = 3 * MS + 2 * D;
+};
+
+// acc[c][reg] = sum_k X[i][k] Y[j][k],  i = 16 r + (lane >> 4) + 4 reg,  j = 16 c + (lane & 15)
+__device__ __forceinline__ void m40_rows_x_rows(const double* X, const double* Y, int r, int lane,
+                                                mfma_f64x4 acc[3]) {
+    const int g = lane >> 4, q = lane & 15;
+    const double* xa = X + min(16 * r + q, M40::D - 1) * M40::LD + 10 * g;
+    double a[10];
+#pragma unroll
+    for (int h = 0; h < 5; ++h) {
+        const double2 v = *reinterpret_cast<const double2*>(xa + 2 * h);
+        a[2 * h] = v.x;
+        a[2 * h + 1] = v.y;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double* yb = Y + min(16 * c + q, M40::D - 1) * M40::LD + 10 * g;
+        double b[10];
+#pragma unroll
+        for (int h = 0; h < 5; ++h) {
+            const double2 v = *reinterpret_cast<const double2*>(yb + 2 * h);
+            b[2 * h] = v.x;
+            b[2 * h + 1] = v.y;
+        }
+        mfma_f64x4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 10; ++k) z = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], z, 0, 0, 0);
+        acc[c] = z;
+    }
+}
+
+// The twelve entries (c, reg) a lane of matrix wavefront r holds: row 16 r + (lane >> 4)
+// + 4 reg, column 16 c + (lane & 15), both clamped to 39.  A clamped entry repeats the
+// computation of the entry it is clamped to with identical operands in identical
+// order, so it holds bit for bit the same value: every entry is stored without a
+// predicate and the duplicates write equal values to equal addresses.
+struct M40Lane {
+    unsigned g[3][4];    // offset in a D x D global matrix
+    unsigned l[3][4];    // offset in an LDS matrix (leading dimension LD)
+    unsigned lt[3][4];   // offset of the transposed entry in an LDS matrix
+    __device__ M40Lane(int r, int lane) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = min(16 * r + (lane >> 4) + 4 * reg, M40::D - 1);
+                const int j = min(16 * c + (lane & 15), M40::D - 1);
+                g[c][reg] = (unsigned)(i * M40::D + j);
+                l[c][reg] = (unsigned)(i * M40::LD + j);
+                lt[c][reg] = (unsigned)(j * M40::LD + i);
+            }
+    }
+};
+
+#define M40_FOR(c, reg) \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)
+
+// Staging of one A matrix: thread t < NSTAGE moves the 16-byte pieces t, t + 200, ...
+__device__ __forceinline__ void m40_prefetch(const double* __restrict__ src, int tid, double (&pre)[8]) {
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    const int t = min(tid, M40::NSTAGE - 1);   // the idle threads repeat a load instead of branching
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double2 v = s2[t + q * M40::NSTAGE];
+        pre[2 * q] = v.x;
+        pre[2 * q + 1] = v.y;
+    }
+}
+
+template <bool TRANSPOSE>
+__device__ __forceinline__ void m40_commit(const double (&pre)[8], int tid, double* dst) {
+    if (tid < M40::NSTAGE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 2 * (tid + q * M40::NSTAGE);
+            const int row = e / M40::D, col = e % M40::D;
+            if (TRANSPOSE) {
+                dst[col * M40::LD + row] = pre[2 * q];
+                dst[(col + 1) * M40::LD + row] = pre[2 * q + 1];
+            } else {
+                *reinterpret_cast<double2*>(dst + row * M40::LD + col) = make_double2(pre[2 * q], pre[2 * q + 1]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward: core/fwd_ode.py:87-132 (euler_nD) with S0, Sigma exactly symmetric
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(M40::NT)
+fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* __restrict__ b,
+                            const double* __restrict__ m0, const double* __restrict__ S0,
+                            const double* __restrict__ Sigma, int sigma_stride, double dt,
+                            double* __restrict__ m_out, double* __restrict__ S_out) {
+    constexpr int D = M40::D, LD = M40::LD, MS = M40::MS, DD = M40::DD;
+    extern __shared__ double lds[];
+    double* Ab = lds;             // A[t]
+    double* Sb = lds + MS;        // S[t]
+    double* Mt = lds + 2 * MS;    // A S, read back transposed
+    double* bv = lds + 3 * MS;    // b[t]
+    double* mvv = bv + D;         // m[t]
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int p = blockIdx.x;
+    const double* Ap = A + (size_t)p * N * DD;
+    const double* bp = b + (size_t)p * N * D;
+    const double* S0p = S0 + (size_t)p * DD;
+    const double* Sgp = Sigma + (size_t)p * sigma_stride;
+    double* mo = m_out + (size_t)p * N * D;
+    double* So = S_out + (size_t)p * N * DD;
+    const M40Lane L(wid < 3 ? wid : 0, lane);
+    const int vl = min(lane, D - 1);
+
+    double s[3][4], sig[3][4];
+    M40_FOR(c, reg) {
+        s[c][reg] = S0p[L.g[c][reg]];
+        sig[c][reg] = Sgp[L.g[c][reg]];
+    }
+    for (int e = tid; e < DD; e += M40::NT) {
+        const int o = (e / D) * LD + (e % D);
+        Ab[o] = Ap[e];
+        const double sv = S0p[e];
+        Sb[o] = sv;
+        So[e] = sv;
+    }
+    double mreg = m0[(size_t)p * D + vl];
+    if (wid == 3 && lane < D) {
+        mvv[lane] = mreg;
+        mo[lane] = mreg;
+        bv[lane] = bp[lane];
+    }
+    // two-deep register prefetch: set A holds row t+1, set B row t+2
+    double preA[8], preB[8];
+    const int r1 = N > 1 ? 1 : 0, r2 = N > 2 ? 2 : N - 1;
+    m40_prefetch(Ap + (size_t)r1 * DD, tid, preA);
+    m40_prefetch(Ap + (size_t)r2 * DD, tid, preB);
+    double bA = bp[(size_t)r1 * D + vl], bB = bp[(size_t)r2 * D + vl];
+
+    auto step = [&](int t, double (&pre)[8], double& bnext) __attribute__((always_inline)) {
+        M40_STAMP(0);
+        __syncthreads();                       // A[t], S[t], m[t], b[t] are in LDS
+        M40_STAMP(1);
+        mfma_f64x4 acc[3];
+        if (wid < 3) {
+            m40_rows_x_rows(Ab, Sb, wid, lane, acc);
+            M40_STAMP(2);
+            M40_FOR(c, reg) Mt[L.l[c][reg]] = acc[c][reg];
+            M40_STAMP(3);
+        } else if (lane < D) {
+            const double* row = Ab + lane * LD;
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll 5
+            for (int k = 0; k < D; k += 2) {
+                const double2 av = *reinterpret_cast<const double2*>(row + k);
+                d0 = fma(av.x, mvv[k], d0);
+                d1 = fma(av.y, mvv[k + 1], d1);
+            }
+            const double f1 = -(d0 + d1) + bv[lane];               // core/fwd_ode.py:44
+            mreg = mreg + f1 * dt;
+            mo[(size_t)(t + 1) * D + lane] = mreg;
+        }
+        __syncthreads();                       // A S complete; A[t], S[t], m[t] no longer read
+        M40_STAMP(4);
+        // Stage A[t+1] and issue the next prefetch before the stores of S[t+1]: the wait
+        // for the prefetched registers then never has to cover stores just issued.
+        m40_commit<false>(pre, tid, Ab);
+        M40_STAMP(5);
+        const int tp = (t + 3 < N) ? t + 3 : N - 1;
+        m40_prefetch(Ap + (size_t)tp * DD, tid, pre);
+        const double bcommit = bnext;
+        bnext = bp[(size_t)tp * D + vl];
+        M40_STAMP(6);
+        if (wid < 3) {
+            double* Sn = So + (size_t)(t + 1) * DD;
+            M40_FOR(c, reg) {
+                const double mt = Mt[L.lt[c][reg]];
+                const double k1 = -acc[c][reg] - mt + sig[c][reg];   // core/fwd_ode.py:45
+                const double sn = s[c][reg] + k1 * dt;
+                s[c][reg] = sn;
+                Sb[L.l[c][reg]] = sn;
+                Sn[L.g[c][reg]] = sn;
+            }
+        } else if (lane < D) {
+            mvv[lane] = mreg;
+            bv[lane] = bcommit;
+        }
+        M40_STAMP(7);
+    };
+
+    for (int t = 0; t + 1 < N; t += 2) {
+        step(t, preA, bA);
+        if (t + 2 < N) step(t + 1, preB, bB);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: core/bwd_ode.py:86-129 (euler_nD) with dEsde_dS, the jumps and the
+// terminal state exactly symmetric, jumps given as one matrix plus row flags
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(M40::NT, 2)
+bwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* __restrict__ dEdm,
+                            const double* __restrict__ dEdS, const double* __restrict__ jm,
+                            const int* __restrict__ obs_flag, const double* __restrict__ jumpS,
+                            int jumpS_stride, double dt, const double* __restrict__ lam_last,
+                            const double* __restrict__ Psi_last, double* __restrict__ lam_out,
+                            double* __restrict__ Psi_out) {
+    constexpr int D = M40::D, LD = M40::LD, MS = M40::MS, DD = M40::DD;
+    extern __shared__ double lds[];
+    double* Pb = lds;             // Psi[t]
+    double* At = lds + MS;        // A[t] transposed
+    double* Mt = lds + 2 * MS;    // Psi A, read back transposed
+    double* lamv = lds + 3 * MS;  // lam[t]
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int p = blockIdx.x;
+    const double* Ap = A + (size_t)p * N * DD;
+    const double* gm = dEdm + (size_t)p * N * D;
+    const double* gS = dEdS + (size_t)p * N * DD;
+    const double* jmp = jm + (size_t)p * N * D;
+    double* lo = lam_out + (size_t)p * N * D;
+    double* Po = Psi_out + (size_t)p * N * DD;
+    const M40Lane L(wid < 3 ? wid : 0, lane);
+    const int vl = min(lane, D - 1);
+    const bool jumps = jumpS && obs_flag;
+
+    const double* jSp = jumps ? jumpS + (size_t)p * jumpS_stride : nullptr;
+    double s[3][4], Gt[3][4];
+    M40_FOR(c, reg) {
+        s[c][reg] = Psi_last ? Psi_last[(size_t)p * DD + L.g[c][reg]] : 0.0;
+        Gt[c][reg] = gS[(size_t)(N - 1) * DD + L.g[c][reg]];
+    }
+    {
+        const double* A0 = Ap + (size_t)(N - 1) * DD;
+        double* P0 = Po + (size_t)(N - 1) * DD;
+        for (int e = tid; e < DD; e += M40::NT) {
+            const int row = e / D, col = e % D;
+            At[col * LD + row] = A0[e];
+            const double pv = Psi_last ? Psi_last[(size_t)p * DD + e] : 0.0;
+            Pb[row * LD + col] = pv;
+            P0[e] = pv;
+        }
+    }
+    double lv = lam_last ? lam_last[(size_t)p * D + vl] : 0.0;
+    double gmt = gm[(size_t)(N - 1) * D + vl];
+    if (wid == 3 && lane < D) {
+        lamv[lane] = lv;
+        lo[(size_t)(N - 1) * D + lane] = lv;
+    }
+    // two-deep register prefetch: set A holds row t-1, set B row t-2
+    double preA[8], preB[8];
+    double GA[3][4], GB[3][4];
+    const int r1 = N > 1 ? N - 2 : 0, r2 = N > 2 ? N - 3 : 0;
+    m40_prefetch(Ap + (size_t)r1 * DD, tid, preA);
+    m40_prefetch(Ap + (size_t)r2 * DD, tid, preB);
+    M40_FOR(c, reg) {
+        GA[c][reg] = gS[(size_t)r1 * DD + L.g[c][reg]];
+        GB[c][reg] = gS[(size_t)r2 * DD + L.g[c][reg]];
+    }
+    double gA = gm[(size_t)r1 * D + vl], gB = gm[(size_t)r2 * D + vl];
+
+    auto step = [&](int t, double (&pre)[8], double (&Gpre)[3][4], double& gpre) __attribute__((always_inline)) {
+        __syncthreads();                       // Psi[t], A[t]', lam[t] are in LDS
+        const bool on = jumps && obs_flag[t - 1];
+        const double jmv = jmp[(size_t)(t - 1) * D + vl];
+        mfma_f64x4 acc[3];
+        double lnew = 0.0;
+        if (wid < 3) {
+            m40_rows_x_rows(Pb, At, wid, lane, acc);
+            M40_FOR(c, reg) Mt[L.l[c][reg]] = acc[c][reg];
+        } else if (lane < D) {
+            double d0 = 0.0, d1 = 0.0;     // (A lam)[lane] = sum_q At[q][lane] lam[q]
+#pragma unroll 5
+            for (int k = 0; k < D; k += 2) {
+                d0 = fma(At[k * LD + lane], lamv[k], d0);
+                d1 = fma(At[(k + 1) * LD + lane], lamv[k + 1], d1);
+            }
+            const double f1 = -gmt + (d0 + d1);                     // core/bwd_ode.py:42
+            lnew = lv - f1 * dt + jmv;                              // core/bwd_ode.py:121-124
+            lo[(size_t)(t - 1) * D + lane] = lnew;
+        }
+        __syncthreads();                       // Psi A complete; Psi[t], A[t]', lam[t] no longer read
+        m40_commit<true>(pre, tid, At);
+        const int tp = (t >= 3) ? t - 3 : 0;
+        m40_prefetch(Ap + (size_t)tp * DD, tid, pre);
+        if (wid < 3) {
+            double* Pn = Po + (size_t)(t - 1) * DD;
+            M40_FOR(c, reg) {
+                const double mt = Mt[L.lt[c][reg]];
+                const double k1 = -Gt[c][reg] + (acc[c][reg] + mt);   // core/bwd_ode.py:43
+                double sn = s[c][reg] - k1 * dt;
+                if (on) sn += jSp[L.g[c][reg]];   // observed rows only (:122, :127); uniform branch
+                s[c][reg] = sn;
+                Pb[L.l[c][reg]] = sn;
+                Pn[L.g[c][reg]] = sn;
+                Gt[c][reg] = Gpre[c][reg];
+            }
+        } else if (lane < D) {
+            lamv[lane] = lnew;
+        }
+        lv = lnew;
+        gmt = gpre;
+        M40_FOR(c, reg) Gpre[c][reg] = gS[(size_t)tp * DD + L.g[c][reg]];
+        gpre = gm[(size_t)tp * D + vl];
+    };
+
+    for (int t = N - 1; t >= 1; t -= 2) {
+        step(t, preA, GA, gA);
+        if (t - 1 >= 1) step(t - 1, preB, GB, gB);
+    }
+}
