@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--problems", type=int, default=256, help="problems per GPU")
+    ap.add_argument("--problems", type=int, default=512, help="problems per GPU")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -113,24 +113,34 @@ def main():
     A, b, sde, m0, S0, thetas = synth_problem(D, N, dt, P, 20240 + rank, dev)
     prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
 
-    ev_pairs = []
+    events = {k: [] for k in ("fwd_scan", "esde", "bwd_scan", "grad_assemble")}
     sym_bwd = prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D)
 
+    def timed_call(name, timed, fn):
+        """Run fn between two HIP events recorded on the stream the kernels are launched on
+        (torch's current stream is the one handed to the library)."""
+        if not timed:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        events[name].append((e0, e1))
+        return out
+
     def step(timed):
-        m, S = engine.fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
+        m, S = timed_call("fwd_scan", timed, lambda: engine.fwd_scan(
+            prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd))
         Eobs, dEobs_dm, jumpS = engine.obs_terms(prob, m, S)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        en = engine.esde(prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False)
-        if timed:
-            e1.record()
-            ev_pairs.append((e0, e1))
+        en = timed_call("esde", timed, lambda: engine.esde(
+            prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
         Esde = engine.reduce_energy(en["Esde_t"], prob.w, prob.dt)
-        lam, Psi = engine.bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-                                   obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym_bwd)
+        lam, Psi = timed_call("bwd_scan", timed, lambda: engine.bwd_scan(
+            prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
+            obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym_bwd))
         F = engine.kl0(prob) + Eobs + Esde
-        gLA, gLb = engine.grad_assemble(prob, A, b, m, S, lam, Psi, en["Ef"], en["Edf"])
+        gLA, gLb = timed_call("grad_assemble", timed, lambda: engine.grad_assemble(
+            prob, A, b, m, S, lam, Psi, en["Ef"], en["Edf"]))
         return F, gLA, gLb, en["status"]
 
     def barrier():
@@ -153,12 +163,26 @@ def main():
         elapsed = float(t.item())
     F, gLA, gLb, status = out
     ok = bool(torch.isfinite(F).all().item()) and int(status.max().item()) == 0
-    esde_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev_pairs]))
+    kernel_ms = {k: float(np.mean([a.elapsed_time(b_) for a, b_ in v])) for k, v in events.items()}
+    esde_ms = kernel_ms["esde"]
 
     if rank == 0:
         total_units = world * P * N * args.steps
         bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
         achieved = P * N * bytes_per_unit / (esde_ms * 1e-3) / 1e9
+        # Algorithmic bytes per (problem, time step) of the other three kernels: forward scan reads
+        # A, b and writes m, S; backward scan reads A, dEsde_dS, dEsde_dm, jumps and writes lam, Psi;
+        # gradient assembly reads A, S, Psi and the vectors and writes dL/dA, dL/db.
+        per_unit = {"fwd_scan": 8 * (2 * D * D + 2 * D), "esde": bytes_per_unit,
+                    "bwd_scan": 8 * (3 * D * D + 3 * D), "grad_assemble": 8 * (4 * D * D + 6 * D)}
+        kernels = {k: {"avg_ms": kernel_ms[k], "bytes_per_unit": per_unit[k],
+                       "achieved_GBps": P * N * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9,
+                       "frac": P * N * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                   for k in kernel_ms}
+        # HBM bytes per unit measured with rocprofv3 PMC counters (FETCH_SIZE doubled for the
+        # 16-byte-per-lane reads, WRITE_SIZE as reported) in separate passes at 256 problems:
+        # profiles/r1_pmc_hbm_traffic.txt.  Scaled by the units of this launch.
+        measured_traffic_per_unit = 39873
         line = {
             "metric": "free-energy+grad evals/sec (problems x timesteps), L96 D=40",
             "value": total_units / elapsed,
@@ -171,9 +195,11 @@ def main():
                                    f"{P} problems per GPU (theta grid), F + dL/dA, dL/db",
                        "problems_per_gpu": P, "N": N, "D": D, "sharding": f"problems x{world}"},
             "valid": ok,
-            "roofline": {"kernel": "esde_l96_ut_kernel", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "esde_l96_ut_tiled_kernel<40,false>", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_unit": bytes_per_unit, "avg_ms": esde_ms},
+                         "traffic": measured_traffic_per_unit * P * N, "bytes_per_unit": bytes_per_unit,
+                         "avg_ms": esde_ms},
+            "kernels": kernels,
         }
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(D, dt)
