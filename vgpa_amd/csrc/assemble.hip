@@ -365,6 +365,9 @@ grad_assemble_nd_kernel(int N, int D, const double* __restrict__ A, const double
     }
 }
 
+#define VGPA_SMALL_D_GRAD
+#include "small_d.h"
+
 // Compile-time-D version for diagonal SigInv: 16-byte LDS reads, unrolled product,
 // 16-byte global stores.  EDF_IMPLICIT derives <df/dx> of Lorenz-96 from the mean.
 template <int D, bool EDF_IMPLICIT>
@@ -626,6 +629,13 @@ extern "C" int vgpa_grad_assemble(int P, int N, int D, const double* A, const do
             if (D == 40) { if (implicit96) VGPA_LAUNCH_GT(40, true); else VGPA_LAUNCH_GT(40, false); }
             else { if (implicit96) VGPA_LAUNCH_GT(16, true); else VGPA_LAUNCH_GT(16, false); }
 #undef VGPA_LAUNCH_GT
+        } else if (D >= 2 && D <= 4) {
+            const unsigned grid = (unsigned)((total + 255) / 256);
+#define VGPA_LAUNCH_GS(DD_)                                                                                         \
+    hipLaunchKernelGGL(grad_assemble_small_kernel<DD_>, dim3(grid), dim3(256), 0, st, total, N, A, b, m, S, lam, Psi, \
+                       Ef, Edf, edf_system, theta, theta_stride, SigInv, sig_stride, sig_diag, dt, flags, gLA, gLb)
+            if (D == 2) VGPA_LAUNCH_GS(2); else if (D == 3) VGPA_LAUNCH_GS(3); else VGPA_LAUNCH_GS(4);
+#undef VGPA_LAUNCH_GS
         } else {
             const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 4 * D + 2);
             allow_lds(grad_assemble_nd_kernel, lds);

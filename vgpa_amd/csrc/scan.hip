@@ -875,10 +875,36 @@ void allow_lds(K kernel, size_t bytes) {
 }
 
 #include "scan_mfma.h"
+#define VGPA_SMALL_D_SCANS
+#include "small_d.h"
+
+template <int METHOD>
+bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
+                      const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
+    const unsigned grid = (unsigned)((P + 63) / 64);
+#define VGPA_FS(DD_) hipLaunchKernelGGL((fwd_scan_small_kernel<DD_, METHOD>), dim3(grid), dim3(64), 0, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
+    if (D == 2) VGPA_FS(2); else if (D == 3) VGPA_FS(3); else return false;
+#undef VGPA_FS
+    return true;
+}
+
+template <int METHOD>
+bool launch_bwd_small(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
+                      const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
+                      const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
+    const unsigned grid = (unsigned)((P + 63) / 64);
+#define VGPA_BS(DD_) hipLaunchKernelGGL((bwd_scan_small_kernel<DD_, METHOD>), dim3(grid), dim3(64), 0, st, P, N, A, dEdm, dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out)
+    if (D == 2) VGPA_BS(2); else if (D == 3) VGPA_BS(3); else return false;
+#undef VGPA_BS
+    return true;
+}
 
 template <int METHOD, int DT, bool SYM>
 void launch_fwd(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                 const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
+    if constexpr (DT == 0) {
+        if (launch_fwd_small<METHOD>(P, N, D, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out, st)) return;
+    }
     if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
         const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
         allow_lds(fwd_euler_sym_mfma40_kernel, lds);
@@ -896,6 +922,10 @@ template <int METHOD, int DT, bool SYM>
 void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                 const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                 const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
+    if constexpr (DT == 0) {
+        if (launch_bwd_small<METHOD>(P, N, D, A, dEdm, dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_last,
+                                     Psi_last, lam_out, Psi_out, st)) return;
+    }
     if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
         if (!jS) {
             const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
