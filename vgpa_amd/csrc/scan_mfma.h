@@ -123,6 +123,51 @@ __device__ __forceinline__ void m40_commit(const double (&pre)[8], int tid, doub
 // ---------------------------------------------------------------------------
 // forward: core/fwd_ode.py:87-132 (euler_nD) with S0, Sigma exactly symmetric
 // ---------------------------------------------------------------------------
+// One wavefront's share of a 40 x 40 matrix in 16-byte pieces: piece lane + 64 q.
+struct M40Wave {
+    static constexpr int NQ = 13;                       // ceil(800 / 64)
+    static __device__ __forceinline__ int piece(int lane, int q) { return lane + 64 * q; }
+    static __device__ __forceinline__ bool valid(int lane, int q) { return piece(lane, q) < M40::DD / 2; }
+    static __device__ __forceinline__ int lds_off(int lane, int q) {
+        const int e = 2 * piece(lane, q);
+        return (e / M40::D) * M40::LD + (e % M40::D);
+    }
+    // global -> registers; out-of-range pieces repeat the last one instead of branching
+    static __device__ __forceinline__ void fetch(const double* __restrict__ src, int lane, double (&pre)[2 * NQ]) {
+        const double2* s2 = reinterpret_cast<const double2*>(src);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double2 v = s2[min(piece(lane, q), M40::DD / 2 - 1)];
+            pre[2 * q] = v.x;
+            pre[2 * q + 1] = v.y;
+        }
+    }
+    // registers -> LDS matrix (row-major, or transposed)
+    template <bool TRANSPOSE>
+    static __device__ __forceinline__ void commit(const double (&pre)[2 * NQ], int lane, double* dst) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (valid(lane, q)) {
+                if (TRANSPOSE) {
+                    const int e = 2 * piece(lane, q), row = e / M40::D, col = e % M40::D;
+                    dst[col * M40::LD + row] = pre[2 * q];
+                    dst[(col + 1) * M40::LD + row] = pre[2 * q + 1];
+                } else {
+                    *reinterpret_cast<double2*>(dst + lds_off(lane, q)) = make_double2(pre[2 * q], pre[2 * q + 1]);
+                }
+            }
+        }
+    }
+    // LDS matrix -> global matrix
+    static __device__ __forceinline__ void write_out(const double* src, int lane, double* __restrict__ dst) {
+        double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (valid(lane, q)) d2[piece(lane, q)] = *reinterpret_cast<const double2*>(src + lds_off(lane, q));
+        }
+    }
+};
+
 __global__ void __launch_bounds__(M40::NT)
 fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* __restrict__ b,
                             const double* __restrict__ m0, const double* __restrict__ S0,
@@ -143,14 +188,8 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
     const double* Sgp = Sigma + (size_t)p * sigma_stride;
     double* mo = m_out + (size_t)p * N * D;
     double* So = S_out + (size_t)p * N * DD;
-    const M40Lane L(wid < 3 ? wid : 0, lane);
     const int vl = min(lane, D - 1);
 
-    double s[3][4], sig[3][4];
-    M40_FOR(c, reg) {
-        s[c][reg] = S0p[L.g[c][reg]];
-        sig[c][reg] = Sgp[L.g[c][reg]];
-    }
     for (int e = tid; e < DD; e += M40::NT) {
         const int o = (e / D) * LD + (e % D);
         Ab[o] = Ap[e];
@@ -158,73 +197,78 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
         Sb[o] = sv;
         So[e] = sv;
     }
-    double mreg = m0[(size_t)p * D + vl];
-    if (wid == 3 && lane < D) {
-        mvv[lane] = mreg;
-        mo[lane] = mreg;
-        bv[lane] = bp[lane];
-    }
-    // two-deep register prefetch: set A holds row t+1, set B row t+2
-    double preA[8], preB[8];
-    const int r1 = N > 1 ? 1 : 0, r2 = N > 2 ? 2 : N - 1;
-    m40_prefetch(Ap + (size_t)r1 * DD, tid, preA);
-    m40_prefetch(Ap + (size_t)r2 * DD, tid, preB);
-    double bA = bp[(size_t)r1 * D + vl], bB = bp[(size_t)r2 * D + vl];
 
-    auto step = [&](int t, double (&pre)[8], double& bnext) __attribute__((always_inline)) {
-        M40_STAMP(0);
-        __syncthreads();                       // A[t], S[t], m[t], b[t] are in LDS
-        M40_STAMP(1);
-        mfma_f64x4 acc[3];
-        if (wid < 3) {
-            m40_rows_x_rows(Ab, Sb, wid, lane, acc);
-            M40_STAMP(2);
-            M40_FOR(c, reg) Mt[L.l[c][reg]] = acc[c][reg];
-            M40_STAMP(3);
-        } else if (lane < D) {
-            const double* row = Ab + lane * LD;
-            double d0 = 0.0, d1 = 0.0;
-#pragma unroll 5
-            for (int k = 0; k < D; k += 2) {
-                const double2 av = *reinterpret_cast<const double2*>(row + k);
-                d0 = fma(av.x, mvv[k], d0);
-                d1 = fma(av.y, mvv[k + 1], d1);
-            }
-            const double f1 = -(d0 + d1) + bv[lane];               // core/fwd_ode.py:44
-            mreg = mreg + f1 * dt;
-            mo[(size_t)(t + 1) * D + lane] = mreg;
+    if (wid < 3) {
+        // ---- matrix wavefronts: no global memory traffic inside the time loop ----------
+        const M40Lane L(wid, lane);
+        double s[3][4], sig[3][4];
+        M40_FOR(c, reg) {
+            s[c][reg] = S0p[L.g[c][reg]];
+            sig[c][reg] = Sgp[L.g[c][reg]];
         }
-        __syncthreads();                       // A S complete; A[t], S[t], m[t] no longer read
-        M40_STAMP(4);
-        // Stage A[t+1] and issue the next prefetch before the stores of S[t+1]: the wait
-        // for the prefetched registers then never has to cover stores just issued.
-        m40_commit<false>(pre, tid, Ab);
-        M40_STAMP(5);
-        const int tp = (t + 3 < N) ? t + 3 : N - 1;
-        m40_prefetch(Ap + (size_t)tp * DD, tid, pre);
-        const double bcommit = bnext;
-        bnext = bp[(size_t)tp * D + vl];
-        M40_STAMP(6);
-        if (wid < 3) {
-            double* Sn = So + (size_t)(t + 1) * DD;
+#pragma unroll 1
+        for (int t = 0; t + 1 < N; ++t) {
+            __syncthreads();                   // A[t], S[t] are in LDS
+            mfma_f64x4 acc[3];
+            m40_rows_x_rows(Ab, Sb, wid, lane, acc);
+            M40_FOR(c, reg) Mt[L.l[c][reg]] = acc[c][reg];
+            __syncthreads();                   // A S complete; A[t], S[t] no longer read
             M40_FOR(c, reg) {
                 const double mt = Mt[L.lt[c][reg]];
                 const double k1 = -acc[c][reg] - mt + sig[c][reg];   // core/fwd_ode.py:45
                 const double sn = s[c][reg] + k1 * dt;
                 s[c][reg] = sn;
                 Sb[L.l[c][reg]] = sn;
-                Sn[L.g[c][reg]] = sn;
             }
-        } else if (lane < D) {
-            mvv[lane] = mreg;
-            bv[lane] = bcommit;
         }
-        M40_STAMP(7);
-    };
+        __syncthreads();
+    } else {
+        // ---- memory wavefront: stages A, integrates m, writes S(t) out of LDS -----------
+        double mreg = m0[(size_t)p * D + vl];
+        if (lane < D) {
+            mvv[lane] = mreg;
+            mo[lane] = mreg;
+            bv[lane] = bp[lane];
+        }
+        // two-deep register prefetch: set A holds row t+1, set B row t+2
+        double preA[2 * M40Wave::NQ], preB[2 * M40Wave::NQ];
+        const int r1 = N > 1 ? 1 : 0, r2 = N > 2 ? 2 : N - 1;
+        M40Wave::fetch(Ap + (size_t)r1 * DD, lane, preA);
+        M40Wave::fetch(Ap + (size_t)r2 * DD, lane, preB);
+        double bA = bp[(size_t)r1 * D + vl], bB = bp[(size_t)r2 * D + vl];
 
-    for (int t = 0; t + 1 < N; t += 2) {
-        step(t, preA, bA);
-        if (t + 2 < N) step(t + 1, preB, bB);
+        auto step = [&](int t, double (&pre)[2 * M40Wave::NQ], double& bnext) __attribute__((always_inline)) {
+            __syncthreads();                   // A[t], S[t], m[t], b[t] are in LDS
+            if (t > 0) M40Wave::write_out(Sb, lane, So + (size_t)t * DD);
+            if (lane < D) {
+                const double* row = Ab + lane * LD;
+                double d0 = 0.0, d1 = 0.0;
+#pragma unroll 5
+                for (int k = 0; k < D; k += 2) {
+                    const double2 av = *reinterpret_cast<const double2*>(row + k);
+                    d0 = fma(av.x, mvv[k], d0);
+                    d1 = fma(av.y, mvv[k + 1], d1);
+                }
+                const double f1 = -(d0 + d1) + bv[lane];               // core/fwd_ode.py:44
+                mreg = mreg + f1 * dt;
+                mo[(size_t)(t + 1) * D + lane] = mreg;
+            }
+            __syncthreads();                   // A[t], S[t], m[t] no longer read
+            if (lane < D) {
+                mvv[lane] = mreg;
+                bv[lane] = bnext;
+            }
+            M40Wave::commit<false>(pre, lane, Ab);
+            const int tp = (t + 3 < N) ? t + 3 : N - 1;
+            M40Wave::fetch(Ap + (size_t)tp * DD, lane, pre);
+            bnext = bp[(size_t)tp * D + vl];
+        };
+        for (int t = 0; t + 1 < N; t += 2) {
+            step(t, preA, bA);
+            if (t + 2 < N) step(t + 1, preB, bB);
+        }
+        __syncthreads();
+        if (N > 1) M40Wave::write_out(Sb, lane, So + (size_t)(N - 1) * DD);
     }
 }
 
