@@ -928,7 +928,7 @@ void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const 
     }
     if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
         if (!jS) {
-            const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
+            const size_t lds = sizeof(double) * (M40::LDS_DOUBLES + M40::MS);
             allow_lds(bwd_euler_sym_mfma40_kernel, lds);
             hipLaunchKernelGGL(bwd_euler_sym_mfma40_kernel, dim3(P), dim3(M40::NT), lds, st, N, A, dEdm, dEdS, jm,
                                obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);

@@ -276,7 +276,7 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
 // backward: core/bwd_ode.py:86-129 (euler_nD) with dEsde_dS, the jumps and the
 // terminal state exactly symmetric, jumps given as one matrix plus row flags
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(M40::NT, 2)
+__global__ void __launch_bounds__(M40::NT)
 bwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* __restrict__ dEdm,
                             const double* __restrict__ dEdS, const double* __restrict__ jm,
                             const int* __restrict__ obs_flag, const double* __restrict__ jumpS,
@@ -288,7 +288,8 @@ bwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
     double* Pb = lds;             // Psi[t]
     double* At = lds + MS;        // A[t] transposed
     double* Mt = lds + 2 * MS;    // Psi A, read back transposed
-    double* lamv = lds + 3 * MS;  // lam[t]
+    double* Gb = lds + 3 * MS;    // dEsde_dS[t]
+    double* lamv = lds + 4 * MS;  // lam[t]
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int p = blockIdx.x;
     const double* Ap = A + (size_t)p * N * DD;
@@ -297,71 +298,41 @@ bwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
     const double* jmp = jm + (size_t)p * N * D;
     double* lo = lam_out + (size_t)p * N * D;
     double* Po = Psi_out + (size_t)p * N * DD;
-    const M40Lane L(wid < 3 ? wid : 0, lane);
     const int vl = min(lane, D - 1);
     const bool jumps = jumpS && obs_flag;
-
     const double* jSp = jumps ? jumpS + (size_t)p * jumpS_stride : nullptr;
-    double s[3][4], Gt[3][4];
-    M40_FOR(c, reg) {
-        s[c][reg] = Psi_last ? Psi_last[(size_t)p * DD + L.g[c][reg]] : 0.0;
-        Gt[c][reg] = gS[(size_t)(N - 1) * DD + L.g[c][reg]];
-    }
+
     {
         const double* A0 = Ap + (size_t)(N - 1) * DD;
+        const double* G0 = gS + (size_t)(N - 1) * DD;
         double* P0 = Po + (size_t)(N - 1) * DD;
         for (int e = tid; e < DD; e += M40::NT) {
             const int row = e / D, col = e % D;
             At[col * LD + row] = A0[e];
+            Gb[row * LD + col] = G0[e];
             const double pv = Psi_last ? Psi_last[(size_t)p * DD + e] : 0.0;
             Pb[row * LD + col] = pv;
             P0[e] = pv;
         }
     }
-    double lv = lam_last ? lam_last[(size_t)p * D + vl] : 0.0;
-    double gmt = gm[(size_t)(N - 1) * D + vl];
-    if (wid == 3 && lane < D) {
-        lamv[lane] = lv;
-        lo[(size_t)(N - 1) * D + lane] = lv;
-    }
-    // two-deep register prefetch: set A holds row t-1, set B row t-2
-    double preA[8], preB[8];
-    double GA[3][4], GB[3][4];
-    const int r1 = N > 1 ? N - 2 : 0, r2 = N > 2 ? N - 3 : 0;
-    m40_prefetch(Ap + (size_t)r1 * DD, tid, preA);
-    m40_prefetch(Ap + (size_t)r2 * DD, tid, preB);
-    M40_FOR(c, reg) {
-        GA[c][reg] = gS[(size_t)r1 * DD + L.g[c][reg]];
-        GB[c][reg] = gS[(size_t)r2 * DD + L.g[c][reg]];
-    }
-    double gA = gm[(size_t)r1 * D + vl], gB = gm[(size_t)r2 * D + vl];
 
-    auto step = [&](int t, double (&pre)[8], double (&Gpre)[3][4], double& gpre) __attribute__((always_inline)) {
-        __syncthreads();                       // Psi[t], A[t]', lam[t] are in LDS
-        const bool on = jumps && obs_flag[t - 1];
-        const double jmv = jmp[(size_t)(t - 1) * D + vl];
-        mfma_f64x4 acc[3];
-        double lnew = 0.0;
-        if (wid < 3) {
+    if (wid < 3) {
+        // ---- matrix wavefronts: global memory is touched on observed rows only -----------
+        const M40Lane L(wid, lane);
+        double s[3][4];
+        M40_FOR(c, reg) s[c][reg] = Psi_last ? Psi_last[(size_t)p * DD + L.g[c][reg]] : 0.0;
+#pragma unroll 1
+        for (int t = N - 1; t >= 1; --t) {
+            __syncthreads();                   // Psi[t], A[t]', dEsde_dS[t] are in LDS
+            const bool on = jumps && obs_flag[t - 1];
+            mfma_f64x4 acc[3];
             m40_rows_x_rows(Pb, At, wid, lane, acc);
-            M40_FOR(c, reg) Mt[L.l[c][reg]] = acc[c][reg];
-        } else if (lane < D) {
-            double d0 = 0.0, d1 = 0.0;     // (A lam)[lane] = sum_q At[q][lane] lam[q]
-#pragma unroll 5
-            for (int k = 0; k < D; k += 2) {
-                d0 = fma(At[k * LD + lane], lamv[k], d0);
-                d1 = fma(At[(k + 1) * LD + lane], lamv[k + 1], d1);
+            double Gt[3][4];
+            M40_FOR(c, reg) {
+                Mt[L.l[c][reg]] = acc[c][reg];
+                Gt[c][reg] = Gb[L.l[c][reg]];
             }
-            const double f1 = -gmt + (d0 + d1);                     // core/bwd_ode.py:42
-            lnew = lv - f1 * dt + jmv;                              // core/bwd_ode.py:121-124
-            lo[(size_t)(t - 1) * D + lane] = lnew;
-        }
-        __syncthreads();                       // Psi A complete; Psi[t], A[t]', lam[t] no longer read
-        m40_commit<true>(pre, tid, At);
-        const int tp = (t >= 3) ? t - 3 : 0;
-        m40_prefetch(Ap + (size_t)tp * DD, tid, pre);
-        if (wid < 3) {
-            double* Pn = Po + (size_t)(t - 1) * DD;
+            __syncthreads();                   // Psi A complete; the LDS inputs are no longer read
             M40_FOR(c, reg) {
                 const double mt = Mt[L.lt[c][reg]];
                 const double k1 = -Gt[c][reg] + (acc[c][reg] + mt);   // core/bwd_ode.py:43
@@ -369,20 +340,53 @@ bwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
                 if (on) sn += jSp[L.g[c][reg]];   // observed rows only (:122, :127); uniform branch
                 s[c][reg] = sn;
                 Pb[L.l[c][reg]] = sn;
-                Pn[L.g[c][reg]] = sn;
-                Gt[c][reg] = Gpre[c][reg];
             }
-        } else if (lane < D) {
-            lamv[lane] = lnew;
         }
-        lv = lnew;
-        gmt = gpre;
-        M40_FOR(c, reg) Gpre[c][reg] = gS[(size_t)tp * DD + L.g[c][reg]];
-        gpre = gm[(size_t)tp * D + vl];
-    };
-
-    for (int t = N - 1; t >= 1; t -= 2) {
-        step(t, preA, GA, gA);
-        if (t - 1 >= 1) step(t - 1, preB, GB, gB);
+        __syncthreads();
+    } else {
+        // ---- memory wavefront: stages A' and dEsde_dS, integrates lam, writes Psi(t) out ----
+        double lv = lam_last ? lam_last[(size_t)p * D + vl] : 0.0;
+        double gmt = gm[(size_t)(N - 1) * D + vl];
+        if (lane < D) {
+            lamv[lane] = lv;
+            lo[(size_t)(N - 1) * D + lane] = lv;
+        }
+        // register prefetch one step deep: row t-1 is fetched while row t is integrated
+        double preA[2 * M40Wave::NQ], preG[2 * M40Wave::NQ];
+        const int r1 = N > 1 ? N - 2 : 0;
+        M40Wave::fetch(Ap + (size_t)r1 * DD, lane, preA);
+        M40Wave::fetch(gS + (size_t)r1 * DD, lane, preG);
+        double gnext = gm[(size_t)r1 * D + vl];
+        double jnext = jmp[(size_t)r1 * D + vl];
+#pragma unroll 1
+        for (int t = N - 1; t >= 1; --t) {
+            __syncthreads();                   // Psi[t], A[t]', lam[t] are in LDS
+            if (t < N - 1) M40Wave::write_out(Pb, lane, Po + (size_t)t * DD);
+            double lnew = 0.0;
+            if (lane < D) {
+                double d0 = 0.0, d1 = 0.0;     // (A lam)[lane] = sum_q At[q][lane] lam[q]
+#pragma unroll 5
+                for (int k = 0; k < D; k += 2) {
+                    d0 = fma(At[k * LD + lane], lamv[k], d0);
+                    d1 = fma(At[(k + 1) * LD + lane], lamv[k + 1], d1);
+                }
+                const double f1 = -gmt + (d0 + d1);                     // core/bwd_ode.py:42
+                lnew = lv - f1 * dt + jnext;                            // core/bwd_ode.py:121-124
+                lo[(size_t)(t - 1) * D + lane] = lnew;
+            }
+            __syncthreads();                   // Psi[t], A[t]', dEsde_dS[t], lam[t] no longer read
+            if (lane < D) lamv[lane] = lnew;
+            lv = lnew;
+            gmt = gnext;
+            M40Wave::commit<true>(preA, lane, At);
+            M40Wave::commit<false>(preG, lane, Gb);
+            const int tp = (t >= 2) ? t - 2 : 0;
+            M40Wave::fetch(Ap + (size_t)tp * DD, lane, preA);
+            M40Wave::fetch(gS + (size_t)tp * DD, lane, preG);
+            gnext = gm[(size_t)tp * D + vl];
+            jnext = jmp[(size_t)tp * D + vl];
+        }
+        __syncthreads();
+        if (N > 1) M40Wave::write_out(Pb, lane, Po);
     }
 }
