@@ -2,8 +2,10 @@
 // workgroup per (problem, time step), all D x D operands in LDS.
 //
 // Phases (block barriers between them unless noted):
-//   1  stage A(t), S(t), m into LDS (16-byte coalesced loads)
-//   2  <f>, A m - b, optionally the dense <df/dx>
+//   1  load S(t) and A(t) (16-byte coalesced loads); S(t) and m go to LDS, A(t) waits in
+//      registers until after phase 3 so that its latency hides behind the pivot chain
+//   2  <f>, A m - b, optionally the dense <df/dx> (the covariance term before phase 3,
+//      the rest after A(t) has been put into LDS)
 //   3  blocked Cholesky S = L L' (block width 8).  Per block column: update by all
 //      threads, barrier, then ONE wavefront factors the 8x8 diagonal block, inverts
 //      the factor and solves the row panel below it (wave-synchronous, cross-lane
@@ -77,7 +79,7 @@ __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_RE
 #ifdef VGPA_STAMPS
 // Diagnostic build only: per-phase cycle counts of one workgroup, lane 0.
 __device__ unsigned long long g_l96_stamps[32];
-#define VGPA_STAMP(k) do { if (blockIdx.x == 1000 && threadIdx.x == 0) g_l96_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VGPA_STAMP(k) do { if (blockIdx.x == 60000 && threadIdx.x == 0) g_l96_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VGPA_STAMP(k) do { } while (0)
 #endif
@@ -110,18 +112,31 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
     const double theta = a.theta[(size_t)p * a.theta_stride];
 
     VGPA_STAMP(0);
-    // ---- phase 1 ----------------------------------------------------------
+    // ---- phase 1: S(t) goes to LDS at once; A(t) stays in registers until the ---------
+    // factorisation is done, so that its HBM latency hides behind the pivot chain
+    constexpr int NQ = (DD / 2 + NT - 1) / NT;
+    double apx[NQ], apy[NQ];
     {
         const double2* Ag = reinterpret_cast<const double2*>(a.A + e * DD);
         const double2* Sg = reinterpret_cast<const double2*>(a.S + e * DD);
+        double spx[NQ], spy[NQ];
 #pragma unroll
-        for (int q0 = 0; q0 < DD / 2; q0 += NT) {
-            const int q = q0 + tid;
-            if (q < DD / 2) {
-                const int o = ((2 * q) / D) * LD + ((2 * q) % D);
-                *reinterpret_cast<double2*>(Am + o) = Ag[q];
-                *reinterpret_cast<double2*>(Lm + o) = Sg[q];
-            }
+        for (int i = 0; i < NQ; ++i) {
+            const double2 v = Sg[min(i * NT + tid, DD / 2 - 1)];
+            spx[i] = v.x;
+            spy[i] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const double2 v = Ag[min(i * NT + tid, DD / 2 - 1)];
+            apx[i] = v.x;
+            apy[i] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = i * NT + tid;
+            if (q < DD / 2)
+                *reinterpret_cast<double2*>(Lm + ((2 * q) / D) * LD + ((2 * q) % D)) = make_double2(spx[i], spy[i]);
         }
         if (tid < D) {
             mv[tid] = a.m[e * D + tid];
@@ -132,45 +147,12 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
     __syncthreads();
 
     VGPA_STAMP(1);
-    // ---- phase 2 ----------------------------------------------------------
+    // ---- phase 2a: the covariance term of <f>, before S is overwritten by its factor ----
+    double Cxx = 0.0;
     if (tid < D) {
         const int l = tid;
         const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
-        double am0 = 0.0, am1 = 0.0;
-#pragma unroll 5
-        for (int k = 0; k < D; k += 2) {
-            const double2 av = *reinterpret_cast<const double2*>(Am + l * LD + k);
-            am0 = fma(av.x, mv[k], am0);
-            am1 = fma(av.y, mv[k + 1], am1);
-        }
-        const double base = (am0 + am1) - a.b[e * D + l];
-        basev[l] = base;
-        const double Cxx = Lm[f1 * LD + b1] - Lm[b2 * LD + b1];
-        const double f0 = (mv[f1] - mv[b2]) * mv[b1] - mv[l] + theta;   // drift at the mean
-        const double Ef = Cxx + f0;
-        a.Ef[e * D + l] = Ef;
-        if (a.dth_t) a.dth_t[e * D + l] = Ef + base;
-        const double r0 = f0 + base;
-        a0v[l] = r0 * r0;
-    }
-    if (a.Edf) {
-        // Jacobian of the drift at the mean; row i is filled in the order
-        // [i] = -1, [i+1] = m[i-1], [i-2] = -m[i-1], [i-1] = m[i+1] - m[i-2].
-        double* E = a.Edf + e * DD;
-#pragma unroll
-        for (int q0 = 0; q0 < DD; q0 += NT) {
-            const int q = q0 + tid;
-            if (q < DD) {
-                const int i = q / D, j = q % D;
-                const int jf1 = (i + 1) % D, jb1 = (i + D - 1) % D, jb2 = (i + D - 2) % D;
-                double v = 0.0;
-                if (j == i) v = -1.0;
-                if (j == jf1) v = mv[jb1];
-                if (j == jb2) v = -mv[jb1];
-                if (j == jb1) v = mv[jf1] - mv[jb2];
-                E[q] = v;
-            }
-        }
+        Cxx = Lm[f1 * LD + b1] - Lm[b2 * LD + b1];
     }
     __syncthreads();
 
@@ -264,6 +246,53 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
         __syncthreads();
         if (sc[0] != 0.0) break;   // uniform: every thread reads the same flag
     }
+    VGPA_STAMP(3);
+    // ---- A(t) into LDS, then phase 2b: <f>, A m - b, optionally the dense <df/dx> -------
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = i * NT + tid;
+        if (q < DD / 2)
+            *reinterpret_cast<double2*>(Am + ((2 * q) / D) * LD + ((2 * q) % D)) = make_double2(apx[i], apy[i]);
+    }
+    __syncthreads();
+    if (tid < D) {
+        const int l = tid;
+        const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
+        double am0 = 0.0, am1 = 0.0;
+#pragma unroll 5
+        for (int k = 0; k < D; k += 2) {
+            const double2 av = *reinterpret_cast<const double2*>(Am + l * LD + k);
+            am0 = fma(av.x, mv[k], am0);
+            am1 = fma(av.y, mv[k + 1], am1);
+        }
+        const double base = (am0 + am1) - a.b[e * D + l];
+        basev[l] = base;
+        const double f0 = (mv[f1] - mv[b2]) * mv[b1] - mv[l] + theta;   // drift at the mean
+        const double Ef = Cxx + f0;
+        a.Ef[e * D + l] = Ef;
+        if (a.dth_t) a.dth_t[e * D + l] = Ef + base;
+        const double r0 = f0 + base;
+        a0v[l] = r0 * r0;
+    }
+    if (a.Edf) {
+        // Jacobian of the drift at the mean; row i is filled in the order
+        // [i] = -1, [i+1] = m[i-1], [i-2] = -m[i-1], [i-1] = m[i+1] - m[i-2].
+        double* E = a.Edf + e * DD;
+#pragma unroll
+        for (int q0 = 0; q0 < DD; q0 += NT) {
+            const int q = q0 + tid;
+            if (q < DD) {
+                const int i = q / D, j = q % D;
+                const int jf1 = (i + 1) % D, jb1 = (i + D - 1) % D, jb2 = (i + D - 2) % D;
+                double v = 0.0;
+                if (j == i) v = -1.0;
+                if (j == jf1) v = mv[jb1];
+                if (j == jb2) v = -mv[jb1];
+                if (j == jb1) v = mv[jf1] - mv[jb2];
+                E[q] = v;
+            }
+        }
+    }
     if (sc[0] != 0.0) {
         // Not positive definite.  The reference falls back to diagonal sigma points,
         // which needs a general inverse of S: flag the step for the fallback pass that
@@ -280,7 +309,6 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
         for (int q = tid; q < DD; q += NT) a.dEdS[e * DD + q] = nan;
         return;
     }
-    VGPA_STAMP(3);
     // strict upper triangle of L := 0 (column reads below need no masking)
 #pragma unroll
     for (int q0 = 0; q0 < DD; q0 += NT) {
