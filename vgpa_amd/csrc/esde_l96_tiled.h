@@ -7,9 +7,9 @@
 //   2  <f>, A m - b, optionally the dense <df/dx> (the covariance term before phase 3,
 //      the rest after A(t) has been put into LDS)
 //   3  blocked Cholesky S = L L' (block width 8).  Per block column: update by all
-//      threads, barrier, then ONE wavefront factors the 8x8 diagonal block, inverts
-//      the factor and solves the row panel below it (wave-synchronous, cross-lane
-//      register reads, no block barrier inside), barrier.  The pivot recurrence
+//      threads, barrier, then ONE wavefront factors the 8x8 diagonal block and inverts
+//      the factor (wave-synchronous, cross-lane register reads), barrier, then all
+//      threads solve the row panel below it, barrier.  The pivot recurrence
 //      is the square-root-free one (one reciprocal per pivot on the critical
 //      path); the square roots are taken off the chain.
 //   4  G = A L with 2x4 register tiles and 16-byte LDS reads, then the +/-
@@ -222,29 +222,30 @@ __global__ void __launch_bounds__(256) esde_l96_ut_tiled_kernel(EsdeArgs a) {
                 }
                 if (!ok && lane == 0) sc[0] = 1.0;
             }
-            wave_lds_fence();
-            // row panel: L[i][c0..c0+7] = S'[i][c0..c0+7] T'   for rows i >= c0 + 8
-            const double* T = Tb + J * NB * NB;
-            const int c = lane & 7;
-            double tr[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) tr[k] = T[c * NB + k];               // zero for k > c
-#pragma unroll 1
-            for (int i0 = c0 + NB; i0 < D; i0 += NB) {
-                const int i = i0 + (lane >> 3);
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < NB; k += 2) {
-                    const double2 x = *reinterpret_cast<const double2*>(Lm + i * LD + c0 + k);
-                    acc = fma(x.x, tr[k], acc);
-                    acc = fma(x.y, tr[k + 1], acc);
-                }
-                wave_lds_fence();        // every lane has read the row before it is overwritten
-                Lm[i * LD + c0 + c] = acc;
-            }
         }
         __syncthreads();
         if (sc[0] != 0.0) break;   // uniform: every thread reads the same flag
+        // (c) row panel, all threads: L[i][c0..c0+7] = S'[i][c0..c0+7] T'  for rows i >= c0 + 8.
+        //     The eight threads of a row sit in one wavefront, so every one of them has
+        //     read the row before any of them overwrites its entry.
+        if (c0 + NB < D) {
+            const int i = c0 + NB + tid / NB, c = tid % NB;
+            if (i < D) {
+                const double* T = Tb + J * NB * NB + c * NB;   // zero beyond the diagonal
+                const double* row = Lm + i * LD + c0;
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < NB; k += 2) {
+                    const double2 x = *reinterpret_cast<const double2*>(row + k);
+                    const double2 t = *reinterpret_cast<const double2*>(T + k);
+                    acc0 = fma(x.x, t.x, acc0);
+                    acc1 = fma(x.y, t.y, acc1);
+                }
+                wave_lds_fence();
+                Lm[i * LD + c0 + c] = acc0 + acc1;
+            }
+            __syncthreads();
+        }
     }
     VGPA_STAMP(3);
     // ---- A(t) into LDS, then phase 2b: <f>, A m - b, optionally the dense <df/dx> -------
