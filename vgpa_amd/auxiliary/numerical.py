@@ -40,15 +40,12 @@ def log_det(A):
 
 
 def safelog(x=None):
-    """auxiliary/numerical.py:287-: log with the argument clipped to the range of
-    float64, so that 0 and inf do not produce -inf / inf."""
+    """auxiliary/numerical.py:287-346: log with the argument clipped to [1e-300, 1e300].
+    Off the hot path (no caller on it); kept for drivers that import it."""
     if x is None:
-        print(" [safelog] in debug mode ... exiting:", end="")
+        print("[safelog] in debug mode ... exiting:", end="")
         return None
-    x = np.asarray(x, dtype=np.float64).copy()
-    tiny, huge = np.finfo(np.float64).tiny, np.finfo(np.float64).max
-    x = np.clip(x, tiny, huge)
-    return np.log(x)
+    return np.log(np.clip(np.asarray(x, dtype=np.float64), 1.0e-300, 1.0e+300))
 
 
 def mytrapz(fxt, dt, idx=None):
