@@ -246,6 +246,47 @@ int vgpa_grad_esde_ms(int K, int D, const double* x, const double* Fx, const dou
 int vgpa_mom_gauss(long long n, const double* m, const double* S, int order, int deriv,
                    double* out, void* stream);
 
+/*
+ * Vector algebra of the batched scaled-conjugate-gradient driver: the passes that one
+ * iteration of auxiliary/optimize.py:132-238 `optim_SCG` makes over the parameter-sized
+ * arrays between its two gradient evaluations, for P independent problems at once.
+ *
+ * A parameter array holds n = nA + nb doubles per problem as two contiguous blocks,
+ * [P x nA | P x nb]: its A block and b block are the (P,N,D,D) and (P,N,D) arrays of the
+ * entry points above (nA = N*D*D, nb = N*D).  `mode` (P ints) selects per problem what
+ * a pass does; 0 always means "skip this problem" (nothing is read or written).
+ * Reducing passes take nch in [1,1024] (chunks per row), work (P*2*nch*4 doubles of
+ * scratch) and write out (P,4); unused columns and skipped problems are 0.  The sums
+ * are formed in a fixed order: a call repeated on the same data returns the same bits.
+ *
+ * vgpa_scg_dots        out = {d.g, d.d, g.g}: slope mu and kappa of :150-156 (a direction
+ *                      with d.g >= 0 is replaced by -g: then mu = -g.g, kappa = g.g);
+ *                      mode may be NULL (all problems).
+ * vgpa_scg_step        y = x + coef[p]*d (mode 1), or with d replaced by -g, which is also
+ *                      stored into d (mode 2, :151-153).  The probe point of :158 and the
+ *                      trial point of :170.
+ * vgpa_scg_curvature   out = {d.(g_probe - g)}: theta of :159 times sigma.
+ * vgpa_scg_trial_stats out = {max|alpha[p] d| (:186), g_try.g_try (:196),
+ *                      g_try.(g - g_try) (:221 times mu, after the move of :193-195),
+ *                      sum|g_try|}.
+ * vgpa_scg_update      mode bit 0: x <- x_try, g <- g_try (:188-195); then d <- -g when
+ *                      bit 1 is set (restart, :216-218), else gamma[p]*d - g (:222);
+ *                      out = {d.g, d.d, g.g} of the new pair.
+ */
+int vgpa_scg_dots(int P, long long nA, long long nb, const double* d, const double* g,
+                  const int* mode, int nch, double* work, double* out, void* stream);
+int vgpa_scg_step(int P, long long nA, long long nb, const double* x, double* d, const double* g,
+                  const double* coef, const int* mode, double* y, void* stream);
+int vgpa_scg_curvature(int P, long long nA, long long nb, const double* d, const double* g_probe,
+                       const double* g, const int* mode, int nch, double* work, double* out,
+                       void* stream);
+int vgpa_scg_trial_stats(int P, long long nA, long long nb, const double* d, const double* g,
+                         const double* g_try, const double* alpha, const int* mode, int nch,
+                         double* work, double* out, void* stream);
+int vgpa_scg_update(int P, long long nA, long long nb, double* x, const double* x_try, double* g,
+                    const double* g_try, double* d, const double* gamma, const int* mode, int nch,
+                    double* work, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

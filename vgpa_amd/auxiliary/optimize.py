@@ -277,6 +277,115 @@ def optim_SA(f, x0, gf, options, mParam):
 # ---------------------------------------------------------------------------
 # batched SCG on the device
 # ---------------------------------------------------------------------------
+class _ParamVectors:
+    """Storage convention of the batched SCG driver: a parameter array is one flat
+    tensor [P x nA | P x nb]; its two blocks, viewed as (P,N,D,D) and (P,N,D), are the
+    arrays the evaluation takes, so nothing is packed or unpacked between the optimiser
+    and the kernels."""
+
+    def __init__(self, A0, b0):
+        self.P = A0.shape[0]
+        self.shape_A, self.shape_b = tuple(A0.shape), tuple(b0.shape)
+        self.nA, self.nb = A0[0].numel(), b0[0].numel()
+        self.n = self.nA + self.nb
+        self.dev = A0.device
+
+    def new(self):
+        import torch
+        return torch.zeros((self.P * self.n,), dtype=torch.float64, device=self.dev)
+
+    def parts(self, v):
+        cut = self.P * self.nA
+        return v[:cut].view(self.shape_A), v[cut:].view(self.shape_b)
+
+    def rows(self, v):
+        cut = self.P * self.nA
+        return v[:cut].view(self.P, self.nA), v[cut:].view(self.P, self.nb)
+
+
+class _DeviceParamOps(_ParamVectors):
+    """The passes of one SCG iteration as libvgpa_hip.so kernels (vgpa_scg_*)."""
+
+    def __init__(self, A0, b0):
+        import torch
+        super().__init__(A0, b0)
+        self.nch = int(min(128, max(1, -(-max(self.nA, self.nb) // 16384))))
+        self.work = torch.empty((self.P * 2 * self.nch * 4,), dtype=torch.float64, device=self.dev)
+
+    def _reduce(self, name, *ptr_args, mode):
+        import torch
+        from .. import engine
+        out = torch.empty((self.P, 4), dtype=torch.float64, device=self.dev)
+        engine.call(name, self.P, self.nA, self.nb, *[engine._p(t) for t in ptr_args], engine._p(mode), self.nch,
+                    engine._p(self.work), engine._p(out), engine._stream())
+        return out
+
+    def dots(self, d, g, mode=None):
+        return self._reduce("vgpa_scg_dots", d, g, mode=mode)
+
+    def step(self, x, d, g, coef, mode, y):
+        from .. import engine
+        engine.call("vgpa_scg_step", self.P, self.nA, self.nb, engine._p(x), engine._p(d), engine._p(g),
+                    engine._p(coef.contiguous()), engine._p(mode), engine._p(y), engine._stream())
+
+    def curvature(self, d, g_probe, g, mode):
+        return self._reduce("vgpa_scg_curvature", d, g_probe, g, mode=mode)[:, 0]
+
+    def trial_stats(self, d, g, g_try, alpha, mode):
+        return self._reduce("vgpa_scg_trial_stats", d, g, g_try, alpha.contiguous(), mode=mode)
+
+    def update(self, x, x_try, g, g_try, d, gamma, mode):
+        return self._reduce("vgpa_scg_update", x, x_try, g, g_try, d, gamma.contiguous(), mode=mode)
+
+
+class _TorchParamOps(_ParamVectors):
+    """The same passes written with torch operations: the statement of what each
+    vgpa_scg_* kernel computes.  scg_batched uses it only for host tensors, which only
+    happens with an injected ``evaluate`` (tests of the recursion logic); device tensors
+    always take the kernels."""
+
+    def _dot(self, a, b):
+        (aA, ab), (bA, bb) = self.rows(a), self.rows(b)
+        return (aA * bA).sum(dim=1) + (ab * bb).sum(dim=1)
+
+    def _out(self, cols, mode):
+        import torch
+        out = torch.zeros((self.P, 4), dtype=torch.float64, device=self.dev)
+        for k, c in enumerate(cols):
+            out[:, k] = c if mode is None else torch.where(mode != 0, c, torch.zeros_like(c))
+        return out
+
+    def dots(self, d, g, mode=None):
+        return self._out([self._dot(d, g), self._dot(d, d), self._dot(g, g)], mode)
+
+    def step(self, x, d, g, coef, mode, y):
+        import torch
+        for xs, ds, gs, ys in zip(self.rows(x), self.rows(d), self.rows(g), self.rows(y)):
+            m = mode.unsqueeze(1)
+            ds.copy_(torch.where(m == 2, -gs, ds))
+            ys.copy_(torch.where(m != 0, xs + coef.unsqueeze(1) * ds, ys))
+
+    def curvature(self, d, g_probe, g, mode):
+        return self._out([self._dot(d, g_probe - g)], mode)[:, 0]
+
+    def trial_stats(self, d, g, g_try, alpha, mode):
+        step_max = sum_abs = None
+        for ds, ts in zip(self.rows(d), self.rows(g_try)):
+            sm, sa = (alpha.unsqueeze(1) * ds).abs().amax(dim=1), ts.abs().sum(dim=1)
+            step_max = sm if step_max is None else step_max.maximum(sm)
+            sum_abs = sa if sum_abs is None else sum_abs + sa
+        return self._out([step_max, self._dot(g_try, g_try), self._dot(g_try, g - g_try), sum_abs], mode)
+
+    def update(self, x, x_try, g, g_try, d, gamma, mode):
+        import torch
+        moved, restart = ((mode & 1) != 0).unsqueeze(1), ((mode & 2) != 0).unsqueeze(1)
+        for xs, xt, gs, gt, ds in zip(self.rows(x), self.rows(x_try), self.rows(g), self.rows(g_try), self.rows(d)):
+            xs.copy_(torch.where(moved, xt, xs))
+            gs.copy_(torch.where(moved, gt, gs))
+            ds.copy_(torch.where(restart, -gs, torch.where(moved, gamma.unsqueeze(1) * ds - gs, ds)))
+        return self.dots(d, g, mode)
+
+
 def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, disp=False):
     """SCG for the P problems of ``prob`` (an ``engine.Problem``) at once.
 
@@ -285,8 +394,11 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     (optimize.py:132-238) -- its own accept / reject decisions, scale beta, restarts
     after n accepted steps and termination tests; finished problems are frozen while
     the others continue.  The work per iteration is one batched gradient evaluation at
-    the probe points and one at the trial points (the reference evaluates F a third
-    time at the accepted point, which is the trial point again: that value is reused).
+    the probe points, one at the trial points (the reference evaluates F a third time
+    at the accepted point, which is the trial point again: that value is reused), and
+    five passes over the parameter arrays (vgpa_scg_step twice, vgpa_scg_curvature,
+    vgpa_scg_trial_stats, vgpa_scg_update).  The gradient before the last accepted step
+    is needed only through sum|g| (the 'gradx' column), which is kept as a scalar.
 
     ``evaluate(A, b, need_grad)`` -> (F (P,), grad (P,n) or None) replaces the device
     evaluation (used by tests); by default it is engine.free_energy + engine.gradient.
@@ -298,40 +410,41 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     import torch
     from .. import engine
 
-    P = A0.shape[0]
-    shape_A, shape_b = A0.shape, b0.shape
-    nA = A0[0].numel()
-    n = nA + b0[0].numel()
-    dev, f64 = A0.device, torch.float64
+    ops = (_DeviceParamOps if A0.is_cuda else _TorchParamOps)(A0, b0)
+    if not A0.is_cuda and evaluate is None:
+        raise RuntimeError("scg_batched evaluates on the HIP device: A0, b0 must be device tensors")
+    P, n, nA = ops.P, ops.n, ops.nA
+    dev, f64, i32 = ops.dev, torch.float64, torch.int32
 
-    def split(x):
-        return x[:, :nA].reshape(shape_A).contiguous(), x[:, nA:].reshape(shape_b).contiguous()
+    def fg(v, g_out):
+        """F at the parameter array v; the gradient goes into g_out."""
+        A, b = ops.parts(v)
+        if evaluate is None:
+            st = engine.free_energy(prob, A, b, want_edf=prob.D == 1 or prob.system < 0, need_adjoint=True)
+            engine.gradient(prob, A, b, st, out=ops.parts(g_out))
+            return st.F
+        F, grad = evaluate(A, b, True)
+        gA, gb = ops.rows(g_out)
+        gA.copy_(grad[:, :nA])
+        gb.copy_(grad[:, nA:])
+        return F
 
-    if evaluate is None:
-        def evaluate(A, b, need_grad):
-            st = engine.free_energy(prob, A, b, want_edf=prob.D == 1 or prob.system < 0, need_adjoint=need_grad)
-            if not need_grad:
-                return st.F, None
-            gLA, gLb = engine.gradient(prob, A, b, st)
-            return st.F, torch.cat((gLA.reshape(P, -1), gLb.reshape(P, -1)), dim=1)
-
-    def fg(x, need_grad=True):
-        A, b = split(x)
-        return evaluate(A, b, need_grad)
-
-    def dot(a, b):
-        return (a * b).sum(dim=1)
-
-    x = torch.cat((A0.reshape(P, -1), b0.reshape(P, -1)), dim=1).to(f64).clone()
+    x, y, g, g_try, d = ops.new(), ops.new(), ops.new(), ops.new(), ops.new()
+    for dst, src in zip(ops.parts(x) + ops.parts(y), (A0, b0, A0, b0)):
+        dst.copy_(src)           # y always holds valid parameters, also in rows a pass skips
     stat = dict(Fx=torch.zeros((nit, P), dtype=f64, device=dev), beta=torch.zeros((nit, P), dtype=f64, device=dev),
                 gradx=torch.zeros((nit, P), dtype=f64, device=dev),
                 MaxIt=torch.full((P,), nit, dtype=torch.int64, device=dev),
                 f_eval=torch.ones((P,), dtype=torch.int64, device=dev),
                 g_eval=torch.ones((P,), dtype=torch.int64, device=dev))
 
-    f_cur, g_new = fg(x)
-    f_old, g_old = f_cur.clone(), g_new.clone()
-    d = -g_new
+    zeros = torch.zeros((P,), dtype=f64, device=dev)
+    every = torch.ones((P,), dtype=i32, device=dev)
+    f_cur = fg(x, g)
+    f_old = f_cur.clone()
+    absg_new = ops.trial_stats(g, g, g, zeros, every)[:, 3]
+    absg_old = absg_new.clone()
+    slopes = ops.update(x, x, g, g, d, zeros, 2 * every)          # d = -g; {d.g, d.d, g.g}
     accepted = torch.ones((P,), dtype=torch.bool, device=dev)
     active = torch.ones((P,), dtype=torch.bool, device=dev)
     n_acc = torch.zeros((P,), dtype=torch.int64, device=dev)
@@ -341,7 +454,6 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     theta = torch.zeros((P,), dtype=f64, device=dev)
     f_final = f_cur.clone()
     sigma0, beta_lo, beta_hi = 1.0e-3, 1.0e-15, 1.0e+100
-    col = lambda v: v.unsqueeze(1)   # noqa: E731
 
     def finish(mask, j, value):
         """Freeze the problems in ``mask`` with iteration count j and final value."""
@@ -355,19 +467,20 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
         if not bool(active.any().item()):
             break
         probe = accepted & active
-        # slope / curvature for the problems whose last step was accepted
-        mu_new = dot(d, g_new)
-        uphill = probe & (mu_new >= 0.0)
-        d = torch.where(col(uphill), -g_new, d)
-        mu_new = torch.where(uphill, dot(d, g_new), mu_new)
-        mu = torch.where(probe, mu_new, mu)
-        kappa = torch.where(probe, dot(d, d), kappa)
+        # slope / curvature for the problems whose last step was accepted (optimize.py:150-156)
+        dg, dd, gg = slopes[:, 0], slopes[:, 1], slopes[:, 2]
+        uphill = probe & (dg >= 0.0)
+        mu = torch.where(probe, torch.where(uphill, -gg, dg), mu)
+        kappa = torch.where(probe, torch.where(uphill, gg, dd), kappa)
         finish(probe & (kappa < _EPS), j, f_cur)
         probe = probe & active
-        sigma = torch.where(probe, sigma0 / torch.sqrt(kappa), torch.zeros_like(kappa))
+        uphill = uphill & probe
+        sigma = torch.where(probe, sigma0 / torch.sqrt(kappa), zeros)
         if bool(probe.any().item()):
-            _, g_probe = fg(x + col(sigma) * d)
-            theta = torch.where(probe, dot(d, g_probe - g_new) / sigma, theta)   # optimize.py:159
+            pmode = probe.to(i32) + uphill.to(i32)
+            ops.step(x, d, g, sigma, pmode, y)                                   # optimize.py:158
+            fg(y, g_try)
+            theta = torch.where(probe, ops.curvature(d, g_try, g, pmode) / sigma, theta)   # :159
             stat["f_eval"] += probe.long()
             stat["g_eval"] += probe.long()
 
@@ -375,36 +488,35 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
         fix = (delta <= 0) & active
         delta = torch.where(fix, beta * kappa, delta)
         beta = torch.where(fix, beta - theta / kappa, beta)
-        alpha = torch.where(active, -(mu / delta), torch.zeros_like(mu))
+        alpha = torch.where(active, -(mu / delta), zeros)
 
-        x_try = x + col(alpha) * d
-        f_try, g_try = fg(x_try)
+        ops.step(x, d, g, alpha, active.to(i32), y)                              # optimize.py:170
+        f_try = fg(y, g_try)
         stat["f_eval"] += active.long()
 
         ratio = 2.0 * (f_try - f_old) / (alpha * mu)
         ok = (ratio >= 0) & active
         accepted = torch.where(active, ok, accepted)
         n_acc += ok.long()
-        x = torch.where(col(ok), x_try, x)
+        trial = ops.trial_stats(d, g, g_try, alpha, ok.to(i32))
         f_cur = torch.where(ok, f_try, torch.where(active, f_old, f_cur))
-        g_shown = torch.where(col(ok), g_new, g_old)
 
         live = active.clone()
         stat["Fx"][j] = torch.where(live, f_cur, stat["Fx"][j])
         stat["beta"][j] = torch.where(live, beta, stat["beta"][j])
-        stat["gradx"][j] = torch.where(live, g_shown.abs().sum(dim=1), stat["gradx"][j])
+        stat["gradx"][j] = torch.where(live, torch.where(ok, absg_new, absg_old), stat["gradx"][j])
         if disp:
             print(" {0}:\tmin fx={1:.3f}\tactive={2}".format(j, float(f_cur.min().item()), int(live.sum().item())))
 
-        small = ((col(alpha) * d).abs().amax(dim=1) <= xtol) & ((f_try - f_old).abs() <= ftol)
+        small = (trial[:, 0] <= xtol) & ((f_try - f_old).abs() <= ftol)
         finish(ok & small, j, f_try)
         moved = ok & active
         f_old = torch.where(moved, f_try, f_old)
-        g_old = torch.where(col(moved), g_new, g_old)
-        g_new = torch.where(col(moved), g_try, g_new)
+        absg_old = torch.where(moved, absg_new, absg_old)
+        absg_new = torch.where(moved, trial[:, 3], absg_new)
         stat["f_eval"] += moved.long()
         stat["g_eval"] += moved.long()
-        finish(moved & (dot(g_new, g_new) == 0.0), j, f_cur)
+        finish(moved & (trial[:, 1] == 0.0), j, f_cur)
 
         grow = active & (ratio < 0.25)
         beta = torch.where(grow, torch.clamp(4.0 * beta, max=beta_hi), beta)
@@ -412,11 +524,12 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
         beta = torch.where(shrink, torch.clamp(0.5 * beta, min=beta_lo), beta)
 
         restart = active & (n_acc == n)
-        gamma = torch.clamp(dot(g_new, g_old - g_new) / mu, min=0.0)
-        d = torch.where(col(restart), -g_new, torch.where(col(moved & ~restart), col(gamma) * d - g_new, d))
+        gamma = torch.where(moved, torch.clamp(trial[:, 2] / mu, min=0.0), zeros)
+        # every accepted problem moves (also one that has just finished: its x is final)
+        slopes = ops.update(x, y, g, g_try, d, gamma, ok.to(i32) + 2 * restart.to(i32))
         n_acc = torch.where(restart, torch.zeros_like(n_acc), n_acc)
 
     # problems that ran out of iterations report the last accepted value (optimize.py:245)
     f_final = torch.where(active, f_old, f_final)
-    A, b = split(x)
+    A, b = ops.parts(x)
     return A, b, f_final, stat

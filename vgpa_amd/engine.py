@@ -329,12 +329,17 @@ def kl0(prob):
     return prob.kl0_cache
 
 
-def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False):
+def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False, out=None):
     """vgpa_grad_assemble -> gLA (like A), gLb (like b), already times dt.  With
-    ``Edf=None`` the kernel derives <df/dx> from the mean (Lorenz systems only)."""
+    ``Edf=None`` the kernel derives <df/dx> from the mean (Lorenz systems only).
+    ``out=(gLA, gLb)`` writes into existing contiguous tensors."""
     P, N, D = prob.P, prob.N, prob.D
-    gLA = torch.empty_like(A)
-    gLb = torch.empty_like(b)
+    if out is None:
+        gLA, gLb = torch.empty_like(A), torch.empty_like(b)
+    else:
+        gLA, gLb = out
+        if gLA.shape != A.shape or gLb.shape != b.shape or gLA.dtype != F64 or gLb.dtype != F64:
+            raise ValueError("grad_assemble: out tensors must match A and b (float64)")
     flags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
     n_theta = 3 if prob.system in (_lib.SYS_L63, _lib.SYS_L63_UT) else 1
     call("vgpa_grad_assemble", P, N, D, _p(A), _p(b), _p(m), _p(S), _p(lam), _p(Psi), _p(Ef), _p(Edf),
@@ -465,9 +470,9 @@ def free_energy(prob, A, b, want_hyper=False, want_edf=True, need_adjoint=True):
                  status=en["status"], dth=en.get("dth"), dSig=en.get("dSig"))
 
 
-def gradient(prob, A, b, st, outer=False):
+def gradient(prob, A, b, st, outer=False, out=None):
     """core/gradL_Ab.py:156-180 for a batch: (gLA, gLb), already times dt."""
-    return grad_assemble(prob, A, b, st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf, outer=outer)
+    return grad_assemble(prob, A, b, st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf, outer=outer, out=out)
 
 
 def check_status(status):
