@@ -15,6 +15,8 @@
 // which is what the per-sigma-point solves of core/gradEsde_mS.py:44-64 followed by
 // dynamics/sys_lorenz_96_ut.py:238-241 evaluate to (the centre point has z = 0 and
 // the Esde m terms cancel exactly).
+#include <cstdlib>
+
 #include "common.h"
 #include "linalg.h"
 
@@ -730,9 +732,21 @@ void launch_l96_tiled_h(const EsdeArgs& a, size_t total, hipStream_t st) {
     hipLaunchKernelGGL((esde_l96_ut_tiled_kernel<D, HYPER>), dim3((unsigned)total), dim3(256), lds, st, a);
 }
 
+#include "esde_l96_wave.h"
+
+template <bool HYPER>
+void launch_l96_wave40(const EsdeArgs& a, size_t total, hipStream_t st) {
+    const size_t lds = sizeof(double) * L96Wave::LDS_DOUBLES;
+    hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<HYPER>), dim3((unsigned)total), dim3(64), lds, st, a);
+}
+
 template <int D>
 void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
-    if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
+    static const bool use_wave = getenv("VGPA_L96_TILED") == nullptr;
+    if (D == 40 && use_wave) {
+        if (a.dSig_t) launch_l96_wave40<true>(a, total, st);
+        else launch_l96_wave40<false>(a, total, st);
+    } else if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
     else launch_l96_tiled_h<D, false>(a, total, st);
     if (a.status) {
         // steps the tiled kernel flagged as not positive definite

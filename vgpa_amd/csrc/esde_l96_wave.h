@@ -1,0 +1,662 @@
+// Lorenz-96 unscented energy kernel for D = 40: ONE WAVEFRONT per (problem, time step),
+// eight steps in flight per CU, the matrix products on the FP64 matrix cores.
+//
+// Everything a step needs sits in one 40 x 42 LDS matrix `buf` (plus a 16 x 16 scratch
+// tile and a few vectors, 18.7 KB in all) and in registers; there is no block barrier.
+//
+//   buf, lower triangle:  S(t) -> L = chol(S) -> W = L^-1, block by block in place
+//   buf, upper triangle:  the inverses T_J of the 16 x 16 diagonal blocks of L, stored
+//                         transposed and shifted one column to the right:
+//                         T_J[a][b] (b <= a) is buf[16 J + b][16 J + a + 1]
+//   registers:            A(t) as matrix-core operand fragments (loaded straight from
+//                         global memory, in flight during the factorisation), the tiles of
+//                         G = A L, the tiles of dEsde/dS
+//
+// Matrix-core tiles are 16 x 16 on the 40 x 40 matrices padded to 48 x 48 (instruction
+// v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
+// C[(l >> 4) + 4 reg][l & 15]).  The rows of a tile are PERMUTED when they are fed in:
+// operand row rho carries matrix row pi(rho) = 4 (rho & 3) + (rho >> 2), so that the four
+// result registers of a lane are four CONSECUTIVE matrix rows 4 (l >> 4) + reg; the
+// Lorenz-96 drift couples rows d-2 .. d+1, which a lane then reads once for all four.
+// Rows / columns 40..47 do not exist: operand rows are clamped (finite duplicates) or
+// masked to zero and the results are never stored.
+//
+// Phases, all wave-synchronous:
+//   1  issue the loads: m, b, Sigma^-1, S(t) (16-byte coalesced, to LDS), A(t) fragments
+//   2  blocked Cholesky, block width 16.  Diagonal block: every lane owns 4 entries of a
+//      row (row r = l >> 2); per pivot the pivot row of the block and of the accumulated
+//      row operations M is broadcast through LDS and every lane eliminates its row,
+//      which yields U = D L~' and M = L~^-1 together (S = L~ D L~'), hence L = U' D^-1/2
+//      and T = D^-1/2 M.  Panel below: L_IJ = S_IJ T_J' and trailing update
+//      S_IK -= L_IJ L_KJ' on the matrix cores.
+//   3  <f>, A m - b, optionally <df/dx>
+//   4  G = A L on the matrix cores, then the +/- sigma-point residuals of every entry,
+//      reduced over the state index within the lane and across the four lane groups
+//   5  Esde(t), u = v+ - v-, g
+//   6  W = L^-1 in place: W_IJ = -T_I sum_K L_IK W_KJ (matrix cores, one scratch tile)
+//   7  dEsde/dm = (w c / 2) W' u (vector), dEsde/dS = W' diag(g) W (matrix cores).  Both
+//      operands are scaled by sqrt|g_k| (one with the sign of g_k), so that entry (i, j)
+//      and entry (j, i) are sums of identical products in identical order: the result is
+//      bitwise symmetric, as the symmetric backward scan requires.
+//
+// A step whose S(t) is not positive definite is flagged for the fallback pass exactly as
+// by the tiled kernel.  Included by esde.hip inside its anonymous namespace, after
+// esde_l96_tiled.h (shares rcp_refined, rsqrt_refined, wave_lds_fence, wave_sum).
+
+typedef double wv_f64x4 __attribute__((ext_vector_type(4)));
+
+struct L96Wave {
+    static constexpr int D = 40, LD = 42, MS = D * LD, DD = D * D;
+    static constexpr int XLD = 18;                       // scratch tile
+    static constexpr int OFF_X = MS;
+    static constexpr int OFF_PROW = OFF_X + 16 * XLD;    // pivot row of S and of M
+    static constexpr int OFF_VEC = OFF_PROW + 32;
+    static constexpr int VL = 48;                        // vectors: m, A m - b, Sigma^-1, u, sa, sb
+    static constexpr int LDS_DOUBLES = OFF_VEC + 6 * VL;
+};
+
+__device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Cross-lane helpers.  A DPP row rotation moves data inside each row of 16 lanes on the
+// vector ALU (no LDS round trip); the sum over the four rows of 16 lanes is one matrix-core
+// instruction with an all-ones A operand (C[.][c] = sum_k B[k][c], B[k][c] = lane 16 k + c).
+template <int CTRL>
+__device__ __forceinline__ double wv_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes with equal (lane >> 4), in every lane (the lanes add in different
+// orders, so their copies may differ in the last bit: read ONE lane where that matters)
+__device__ __forceinline__ double wv_row_sum(double v) {
+    v += wv_dpp<0x128>(v);   // row_ror:8
+    v += wv_dpp<0x124>(v);   // row_ror:4
+    v += wv_dpp<0x122>(v);   // row_ror:2
+    v += wv_dpp<0x121>(v);   // row_ror:1
+    return v;
+}
+// sum over lanes with equal (lane & 15), in every lane
+__device__ __forceinline__ double wv_col_sum(double v) {
+    const wv_f64x4 z = {0.0, 0.0, 0.0, 0.0};
+    return wv_mfma(1.0, v, z)[0];
+}
+
+// One 16-wide diagonal block of the factorisation (NP valid rows: 16, or 8 for the last).
+// In: the block of the partly updated S in buf.  Out: L_JJ in the lower triangle of the
+// block; T_J = L_JJ^-1 transposed and shifted two columns right in its upper triangle.
+// Lane c < 16 holds column c of the block, lane 16 + c column c of M, the accumulated row
+// operations (M = I at the start).  Per pivot k: the pivot S[k][k] and the multipliers
+// t_i = S[k][i] / S[k][k] are read across lanes into scalar registers, and every lane
+// eliminates its column: x[i] -= t_i x[k].  That leaves U = D L~' in the S lanes and
+// M = L~^-1 in the M lanes (S = L~ D L~'), so L = U' D^-1/2 and T = D^-1/2 M: both are
+// x[i] / sqrt(d_i).  No LDS traffic inside the pivot chain.  Returns false on a pivot <= 0.
+template <int J>
+__device__ __forceinline__ bool wv_factor_diag(double* buf, int lane) {
+    constexpr int LD = L96Wave::LD, c0 = 16 * J, NP = (J == 2) ? 8 : 16;
+    const int c = lane & 15;
+    const bool is_m = (lane & 16) != 0;
+    double x[NP];
+    {
+        const double* src = buf + (c0 + min(c, NP - 1)) * LD + c0;     // column c = row c (symmetric)
+#pragma unroll
+        for (int h = 0; h < NP / 2; ++h) {
+            const double2 v = *reinterpret_cast<const double2*>(src + 2 * h);
+            x[2 * h] = v.x;
+            x[2 * h + 1] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) x[i] = is_m ? ((i == c) ? 1.0 : 0.0) : x[i];
+    }
+    bool ok = true;
+    double pivc = 1.0;             // pivot of row c
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const double piv = readlane_f64(x[k], k);
+        ok = ok && (piv > 0.0);
+        pivc = (c == k) ? piv : pivc;
+        const double tk = x[k] * rcp_refined(piv);
+#pragma unroll
+        for (int i = k + 1; i < NP; ++i) x[i] = fma(-readlane_f64(tk, i), x[k], x[i]);
+    }
+    const double rsc = rsqrt_refined(pivc);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] *= readlane_f64(rsc, i);
+    // S lane c: L[c][k] = x[k] for k <= c, to buf[c0 + c][c0 + k]
+    // M lane c: T[i][c] = x[i] for i >= c, to buf[c0 + c][c0 + i + 2]
+    if (lane < 32 && c < NP) {
+        double* dst = buf + (c0 + c) * LD + c0 + (is_m ? 2 : 0);
+#pragma unroll
+        for (int h = 0; h < NP / 2; ++h) {
+            const bool wr = is_m ? (2 * h + 1 >= c) : (2 * h <= c);
+            if (wr) *reinterpret_cast<double2*>(dst + 2 * h) = make_double2(x[2 * h], x[2 * h + 1]);
+        }
+    }
+    wave_lds_fence();
+    return ok;
+}
+
+template <bool HYPER>
+__global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
+    using C = L96Wave;
+    constexpr int D = C::D, LD = C::LD, DD = C::DD, XLD = C::XLD, VL = C::VL;
+    extern __shared__ double lds[];
+    double* buf = lds;
+    double* Xs = lds + C::OFF_X;
+    double* mv = lds + C::OFF_VEC;
+    double* basev = mv + VL;
+    double* sIv = basev + VL;
+    double* uv = sIv + VL;
+    double* sav = uv + VL;      // sqrt|g|
+    double* sbv = sav + VL;     // sign(g) sqrt|g|
+    const int lane = threadIdx.x;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int pi = 4 * (c16 & 3) + (c16 >> 2);     // matrix row (within a tile) this lane feeds in as operand row c16
+    const size_t e = blockIdx.x;                   // p * N + t
+    const int p = (int)(e / a.N);
+    const double theta = a.theta[(size_t)p * a.theta_stride];
+
+    VGPA_STAMP(16);
+    // ---- phase 1: loads ---------------------------------------------------------------
+    const int lv = min(lane, D - 1);
+    const double m_l = a.m[e * D + lv];
+    const double b_l = a.b[e * D + lv];
+    const double si_l = a.sig_inv_diag[(size_t)p * a.sig_stride + lv];
+    constexpr int NQ = (DD / 2 + 63) / 64;         // 13 sixteen-byte pieces per lane
+    {
+        const double2* Sg = reinterpret_cast<const double2*>(a.S + e * DD);
+        double sx[NQ], sy[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const double2 v = Sg[min(i * 64 + lane, DD / 2 - 1)];
+            sx[i] = v.x;
+            sy[i] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = i * 64 + lane;
+            if (q < DD / 2)
+                *reinterpret_cast<double2*>(buf + ((2 * q) / D) * LD + ((2 * q) % D)) = make_double2(sx[i], sy[i]);
+        }
+    }
+    double af[3][10];                              // A[16 i + pi][4 s + g4]
+    {
+        const double* Ae = a.A + e * DD;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double* row = Ae + min(16 * i + pi, D - 1) * D + g4;
+#pragma unroll
+            for (int s = 0; s < 10; ++s) af[i][s] = row[4 * s];
+        }
+    }
+    if (lane < VL) {
+        mv[lane] = lane < D ? m_l : 0.0;
+        sIv[lane] = lane < D ? si_l : 0.0;
+        basev[lane] = 0.0;
+    }
+    wave_lds_fence();
+
+    // the covariance term of <f>, before S is overwritten by its factor
+    double Cxx = 0.0;
+    {
+        const int l = lv;
+        const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
+        Cxx = buf[f1 * LD + b1] - buf[b2 * LD + b1];
+    }
+    wave_lds_fence();
+
+    VGPA_STAMP(17);
+    // ---- phase 2: blocked Cholesky ------------------------------------------------------
+    // Operand fetchers.  "rows" operands: element [r][k] of a block whose rows are matrix
+    // rows; as A operand the lane feeds row pi, as B operand (the block transposed) row c16.
+    auto rows4 = [&](int row, int col0, double (&o)[4]) {
+        const double* src = buf + min(row, D - 1) * LD + col0 + g4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[s] = src[4 * s];
+    };
+    // B operand T_J': element [k][c] = T_J[c][k], zero above the diagonal
+    auto tjt4 = [&](int J, double (&o)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * s + g4;
+            const double v = buf[(16 * J + k) * LD + 16 * J + c16 + 2];
+            o[s] = (k <= c16) ? v : 0.0;
+        }
+    };
+    auto tile_rd = [&](int I, int K, wv_f64x4& t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = buf[min(16 * I + 4 * g4 + q, D - 1) * LD + 16 * K + c16];
+    };
+    auto tile_wr = [&](int I, int K, const wv_f64x4& t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * I + 4 * g4 + q;
+            if (row < D && 16 * K + c16 < D) buf[row * LD + 16 * K + c16] = t[q];
+        }
+    };
+    bool ok = wv_factor_diag<0>(buf, lane);
+    {
+        // block column 0: panel L_10, L_20 = S_I0 T_0'
+        double t0[4], s10[4], s20[4];
+        tjt4(0, t0);
+        rows4(16 + pi, 0, s10);
+        rows4(32 + pi, 0, s20);
+        wv_f64x4 l10 = {0.0, 0.0, 0.0, 0.0}, l20 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            l10 = wv_mfma(s10[s], t0[s], l10);
+            l20 = wv_mfma(s20[s], t0[s], l20);
+        }
+        wave_lds_fence();
+        tile_wr(1, 0, l10);
+        tile_wr(2, 0, l20);
+        wave_lds_fence();
+    }
+    {
+        // S_11 -= L_10 L_10',  S_21 -= L_20 L_10'
+        double a10[4], a20[4], b10[4];
+        rows4(16 + pi, 0, a10);
+        rows4(32 + pi, 0, a20);
+        rows4(16 + c16, 0, b10);
+        wv_f64x4 s11, s21;
+        tile_rd(1, 1, s11);
+        tile_rd(2, 1, s21);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s11 = wv_mfma(-a10[s], b10[s], s11);
+            s21 = wv_mfma(-a20[s], b10[s], s21);
+        }
+        wave_lds_fence();
+        tile_wr(1, 1, s11);
+        tile_wr(2, 1, s21);
+        wave_lds_fence();
+    }
+    ok = wv_factor_diag<1>(buf, lane) && ok;
+    {
+        // block column 1: panel L_21 = S_21 T_1'
+        double t1[4], s21[4];
+        tjt4(1, t1);
+        rows4(32 + pi, 16, s21);
+        wv_f64x4 l21 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) l21 = wv_mfma(s21[s], t1[s], l21);
+        wave_lds_fence();
+        tile_wr(2, 1, l21);
+        wave_lds_fence();
+    }
+    {
+        // S_22 -= L_20 L_20' + L_21 L_21'
+        double a20[4], b20[4], a21[4], b21[4];
+        rows4(32 + pi, 0, a20);
+        rows4(32 + c16, 0, b20);
+        rows4(32 + pi, 16, a21);
+        rows4(32 + c16, 16, b21);
+        wv_f64x4 s22, s22b = {0.0, 0.0, 0.0, 0.0};
+        tile_rd(2, 2, s22);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s22 = wv_mfma(-a20[s], b20[s], s22);
+            s22b = wv_mfma(-a21[s], b21[s], s22b);
+        }
+        s22 += s22b;
+        wave_lds_fence();
+        tile_wr(2, 2, s22);
+        wave_lds_fence();
+    }
+    ok = wv_factor_diag<2>(buf, lane) && ok;
+
+    VGPA_STAMP(18);
+    // ---- phase 3: <f>, A m - b, optionally the dense <df/dx> ------------------------------
+    {
+        double mk[10];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) mk[s] = mv[4 * s + g4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < 10; s += 2) {
+                t0 = fma(af[i][s], mk[s], t0);
+                t1 = fma(af[i][s + 1], mk[s + 1], t1);
+            }
+            const double t = wv_col_sum(t0 + t1);
+            if (g4 == 0 && 16 * i + pi < D) basev[16 * i + pi] = t;
+        }
+    }
+    wave_lds_fence();
+    double a0 = 0.0;          // squared centre-point residual of component `lane`
+    {
+        const int l = lv;
+        const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
+        const double base = basev[l] - b_l;
+        const double f0 = (mv[f1] - mv[b2]) * mv[b1] - m_l + theta;   // drift at the mean
+        const double Ef = Cxx + f0;
+        wave_lds_fence();
+        if (lane < D) {
+            basev[l] = base;
+            a.Ef[e * D + l] = Ef;
+            if (a.dth_t) a.dth_t[e * D + l] = Ef + base;
+            const double r0 = f0 + base;
+            a0 = r0 * r0;
+        }
+    }
+    wave_lds_fence();
+    if (a.Edf) {
+        // Jacobian of the drift at the mean; row i is filled in the order
+        // [i] = -1, [i+1] = m[i-1], [i-2] = -m[i-1], [i-1] = m[i+1] - m[i-2].
+        double* E = a.Edf + e * DD;
+#pragma unroll 5
+        for (int q = lane; q < DD; q += 64) {
+            const int i = q / D, j = q % D;
+            const int jf1 = (i + 1) % D, jb1 = (i + D - 1) % D, jb2 = (i + D - 2) % D;
+            double v = 0.0;
+            if (j == i) v = -1.0;
+            if (j == jf1) v = mv[jb1];
+            if (j == jb2) v = -mv[jb1];
+            if (j == jb1) v = mv[jf1] - mv[jb2];
+            E[q] = v;
+        }
+    }
+    if (!ok) {
+        // Not positive definite: flag the step for the fallback pass that follows this
+        // kernel and poison its outputs in case there is none.
+        const double nan = __builtin_nan("");
+        if (lane == 0) {
+            a.Esde_t[e] = nan;
+            if (a.status) a.status[e] = VGPA_ST_CHOL_FALLBACK | VGPA_ST_UNSUPPORTED;
+        }
+        if (lane < D) {
+            a.dEdm[e * D + lane] = nan;
+            if (a.dSig_t) a.dSig_t[e * D + lane] = nan;
+        }
+        for (int q = lane; q < DD; q += 64) a.dEdS[e * DD + q] = nan;
+        return;
+    }
+
+    VGPA_STAMP(19);
+    const double kappa = 1.05 * D;
+    const double c2 = D + kappa;
+    const double cs = sqrt(c2);
+    const double w0 = kappa / c2, w1 = 1.0 / (2.0 * c2);
+
+    // ---- phase 4: G = A L, then the sigma-point residuals ---------------------------------
+    double vp[3] = {0.0, 0.0, 0.0}, vm[3] = {0.0, 0.0, 0.0};
+    double mb[3][4] = {};
+    {
+        wv_f64x4 G[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) G[i][j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = 16 * j + c16;
+#pragma unroll
+            for (int s = 4 * j; s < 10; ++s) {
+                const int k = 4 * s + g4;
+                double v = buf[k * LD + col];
+                if (s < 4 * j + 4) v = (k >= col) ? v : 0.0;     // diagonal block: only the lower triangle is L
+#pragma unroll
+                for (int i = 0; i < 3; ++i) G[i][j] = wv_mfma(af[i][s], v, G[i][j]);
+            }
+        }
+    VGPA_STAMP(20);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int d0r = 16 * i + 4 * g4;
+            const bool rows_valid = d0r < D;
+            const int d0 = rows_valid ? d0r : D - 4;
+            int rw[7];
+            double mm[7];
+#pragma unroll
+            for (int w = 0; w < 7; ++w) {
+                rw[w] = (d0 + D - 2 + w) % D;
+                mm[w] = mv[rw[w]];
+            }
+            double bs[4], si[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bs[q] = basev[d0 + q];
+                si[q] = rows_valid ? sIv[d0 + q] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                wave_lds_fence();      // keeps the LDS reads of one tile together (register pressure)
+                const int col = min(16 * j + c16, D - 1);
+                const bool col_valid = 16 * j + c16 < D;
+                double o[7];
+#pragma unroll
+                for (int w = 0; w < 7; ++w) {
+                    const double x = buf[rw[w] * LD + col];
+                    o[w] = (rw[w] >= col) ? cs * x : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // state index d = d0 + q sits at position q + 2 of the 7-row window
+                    const double xm2p = mm[q] + o[q], xm1p = mm[q + 1] + o[q + 1];
+                    const double x0p = mm[q + 2] + o[q + 2], xp1p = mm[q + 3] + o[q + 3];
+                    const double xm2m = mm[q] - o[q], xm1m = mm[q + 1] - o[q + 1];
+                    const double x0m = mm[q + 2] - o[q + 2], xp1m = mm[q + 3] - o[q + 3];
+                    const double fp = (xp1p - xm2p) * xm1p - x0p + theta;
+                    const double fm = (xp1m - xm2m) * xm1m - x0m + theta;
+                    const double cG = cs * G[i][j][q];
+                    const double rp = fp + bs[q] + cG, rm = fm + bs[q] - cG;
+                    const double rp2 = rp * rp, rm2 = rm * rm;
+                    vp[j] = fma(si[q], rp2, vp[j]);
+                    vm[j] = fma(si[q], rm2, vm[j]);
+                    if (HYPER) mb[i][q] += col_valid ? w1 * (rp2 + rm2) : 0.0;
+                }
+            }
+        }
+    }
+    VGPA_STAMP(21);
+    // ---- phase 5: Esde(t), u, g ------------------------------------------------------------
+    {
+        double tot = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            vp[j] = wv_col_sum(vp[j]);
+            vm[j] = wv_col_sum(vm[j]);
+            tot += (16 * j + c16 < D) ? vp[j] + vm[j] : 0.0;
+        }
+        // centre point: component l = lane < 40; sum over the lane groups, then over the row
+        tot = readlane_f64(wv_row_sum(tot), 0);
+        const double v0 = readlane_f64(wv_row_sum(wv_col_sum(lane < D ? si_l * a0 : 0.0)), 0);
+        const double Esde = 0.5 * (w0 * v0 + w1 * tot);
+        if (g4 == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = 16 * j + c16;
+                if (col < D) {
+                    const double gk = 0.125 * (vp[j] + vm[j]) - 0.5 * Esde;
+                    const double sq = sqrt(fabs(gk));
+                    uv[col] = vp[j] - vm[j];
+                    sav[col] = sq;
+                    sbv[col] = copysign(sq, gk);
+                }
+            }
+        }
+        if (lane == 0) {
+            a.Esde_t[e] = Esde;
+            if (a.status) a.status[e] = 0;
+        }
+        if (HYPER && a.dSig_t) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    mb[i][q] = wv_row_sum(mb[i][q]);
+                }
+            // lane (g4, c16 == q) stores row 16 i + 4 g4 + q
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int d = 16 * i + 4 * g4 + c16;
+                double t = mb[i][0];
+                t = (c16 == 1) ? mb[i][1] : t;
+                t = (c16 == 2) ? mb[i][2] : t;
+                t = (c16 == 3) ? mb[i][3] : t;
+                // the centre point: w0 (f0 + base)^2 of component d, held by lane d
+                const double ctr = __shfl(a0, min(d, D - 1), 64);
+                if (c16 < 4 && 16 * i + 4 * g4 < D) a.dSig_t[e * D + d] = w0 * ctr + t;
+            }
+        }
+    }
+    wave_lds_fence();
+
+    VGPA_STAMP(22);
+    // ---- phase 6: W = L^-1 in place ---------------------------------------------------------
+    //   W_10 = -T_1 (L_10 T_0)     W_21 = -T_2 (L_21 T_1)     W_20 = -T_2 (L_20 T_0 + L_21 W_10)
+    {
+        // B operand T_J: element [k][c] = T_J[k][c], zero above the diagonal
+        auto tj4 = [&](int J, double (&o)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 4 * s + g4;
+                const double v = buf[(16 * J + c16) * LD + 16 * J + k + 2];
+                o[s] = (c16 <= k) ? v : 0.0;
+            }
+        };
+        // A operand -T_I: element [rho][k] = -T_I[pi][k] (NV valid rows / columns)
+        auto neg_ti4 = [&](int I, int NV, double (&o)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 4 * s + g4;
+                const double v = buf[min(16 * I + k, D - 1) * LD + 16 * I + pi + 2];
+                o[s] = (k <= pi && pi < NV) ? -v : 0.0;
+            }
+        };
+        auto xs_wr = [&](const wv_f64x4& t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xs[(4 * g4 + q) * XLD + c16] = t[q];
+        };
+        auto xs_rd = [&](double (&o)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o[s] = Xs[(4 * s + g4) * XLD + c16];
+        };
+        const wv_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+        double t0[4], t1[4], l10[4], l20[4], l21[4], nt1[4], nt2[4];
+        tj4(0, t0);
+        tj4(1, t1);
+        rows4(16 + pi, 0, l10);
+        rows4(32 + pi, 0, l20);
+        rows4(32 + pi, 16, l21);
+        neg_ti4(1, 16, nt1);
+        neg_ti4(2, 8, nt2);
+        wv_f64x4 x10 = zero, x20 = zero, x21 = zero;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            x10 = wv_mfma(l10[s], t0[s], x10);
+            x21 = wv_mfma(l21[s], t1[s], x21);
+            x20 = wv_mfma(l20[s], t0[s], x20);
+        }
+        double xb[4], yb[4];
+        wave_lds_fence();
+        xs_wr(x10);
+        wave_lds_fence();
+        xs_rd(xb);
+        wave_lds_fence();
+        xs_wr(x21);
+        wave_lds_fence();
+        xs_rd(yb);
+        wave_lds_fence();
+        wv_f64x4 w10 = zero, w21 = zero;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w10 = wv_mfma(nt1[s], xb[s], w10);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w21 = wv_mfma(nt2[s], yb[s], w21);     // T_2 has 8 columns
+        tile_wr(1, 0, w10);
+        tile_wr(2, 1, w21);
+        wave_lds_fence();
+        double wb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wb[s] = buf[(16 + 4 * s + g4) * LD + c16];      // W_10, B operand
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x20 = wv_mfma(l21[s], wb[s], x20);
+        wave_lds_fence();
+        xs_wr(x20);
+        wave_lds_fence();
+        xs_rd(xb);
+        wv_f64x4 w20 = zero;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w20 = wv_mfma(nt2[s], xb[s], w20);
+        wave_lds_fence();
+        tile_wr(2, 0, w20);
+        // diagonal blocks: W_JJ = T_J, from the shifted upper triangle to its place
+        const int ra = lane >> 2, cb = 4 * (lane & 3);
+        double t[3][4];
+#pragma unroll
+        for (int J = 0; J < 3; ++J)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = cb + q;
+                const bool valid = (b <= ra) && (J < 2 || ra < 8);
+                t[J][q] = valid ? buf[min(16 * J + b, D - 1) * LD + 16 * J + ra + 2] : 0.0;
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int J = 0; J < 3; ++J)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = cb + q;
+                if ((b <= ra) && (J < 2 || ra < 8)) buf[(16 * J + ra) * LD + 16 * J + b] = t[J][q];
+            }
+    }
+    wave_lds_fence();
+
+    VGPA_STAMP(23);
+    // ---- phase 7: dEsde/dm and dEsde/dS -------------------------------------------------------
+    {
+        const int l = lv;
+        double y0 = 0.0, y1 = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < D; k += 2) {
+            const double2 u2 = *reinterpret_cast<const double2*>(uv + k);
+            const double w0k = buf[k * LD + l], w1k = buf[(k + 1) * LD + l];
+            y0 = fma(k >= l ? w0k : 0.0, u2.x, y0);
+            y1 = fma(k + 1 >= l ? w1k : 0.0, u2.y, y1);
+        }
+        if (lane < D) a.dEdm[e * D + l] = 0.5 * w1 * cs * (y0 + y1);
+    }
+    VGPA_STAMP(24);
+    {
+        wv_f64x4 acc[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+            const int k = 4 * s + g4;
+            const double sa = sav[k], sb = sbv[k];
+            const int nt = s / 4 + 1;                // column blocks 0 .. nt-1 reach row k
+            double ao[3], bo[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (t < nt) {
+                    const int ca = 16 * t + pi, cb = 16 * t + c16;
+                    const double wa = buf[k * LD + ca], wb = buf[k * LD + cb];
+                    ao[t] = (k >= ca && ca < D) ? sa * wa : 0.0;
+                    bo[t] = (k >= cb && cb < D) ? sb * wb : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (i < nt && j < nt) acc[i][j] = wv_mfma(ao[i], bo[j], acc[i][j]);
+        }
+    VGPA_STAMP(25);
+        double* Gd = a.dEdS + e * DD;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * i + 4 * g4 + q, col = 16 * j + c16;
+                    if (row < D && col < D) Gd[row * D + col] = acc[i][j][q];
+                }
+    }
+    VGPA_STAMP(26);
+}
