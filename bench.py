@@ -195,7 +195,7 @@ def main():
                                    f"{P} problems per GPU (theta grid), F + dL/dA, dL/db",
                        "problems_per_gpu": P, "N": N, "D": D, "sharding": f"problems x{world}"},
             "valid": ok,
-            "roofline": {"kernel": "esde_l96_ut_tiled_kernel<40,false>", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "esde_l96_ut_wave40_kernel<false>", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic_per_unit * P * N, "bytes_per_unit": bytes_per_unit,
                          "avg_ms": esde_ms},

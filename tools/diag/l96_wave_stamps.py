@@ -22,7 +22,9 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 dbg.vgpa_debug_l96_stamps.argtypes = [ctypes.c_void_p]
 print("rc", dbg.vgpa_debug_l96_stamps(buf))
-t = np.array(list(buf)[16:27], dtype=np.int64)
-names = ["loads", "cholesky", "ef,base", "G=AL", "residuals", "reduce", "W", "dEdm", "dS mfma", "dS store"]
+t = np.array([buf[i] for i in (16, 17, 18, 19, 21, 22, 23, 25, 26)], dtype=np.int64)
+names = ["loads", "cholesky", "ef,base", "G+residuals", "reduce", "W", "dS+dm mfma", "dS store"]
 for n, v in zip(names, np.diff(t)): print(f"{n:12s} {v:8d} ticks")
 print("total", t[-1] - t[0])
+c = np.array([buf[17], buf[27], buf[28], buf[29], buf[30], buf[18]], dtype=np.int64)
+for n, v in zip(["diag0", "panel0+trail0", "diag1", "panel1+trail1", "diag2"], np.diff(c)): print(f"  chol {n:14s} {v:8d}")

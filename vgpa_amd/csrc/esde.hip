@@ -15,8 +15,6 @@
 // which is what the per-sigma-point solves of core/gradEsde_mS.py:44-64 followed by
 // dynamics/sys_lorenz_96_ut.py:238-241 evaluate to (the centre point has z = 0 and
 // the Esde m terms cancel exactly).
-#include <cstdlib>
-
 #include "common.h"
 #include "linalg.h"
 
@@ -734,22 +732,37 @@ void launch_l96_tiled_h(const EsdeArgs& a, size_t total, hipStream_t st) {
 
 #include "esde_l96_wave.h"
 
-template <bool HYPER>
-void launch_l96_wave40(const EsdeArgs& a, size_t total, hipStream_t st) {
+// The wavefront-per-step kernel takes a (steps x problems) grid; more problems than a grid
+// dimension holds are launched in slices of the problem axis.
+void launch_l96_wave40(const EsdeArgs& a, hipStream_t st) {
+    constexpr int MAXP = 65535;
     const size_t lds = sizeof(double) * L96Wave::LDS_DOUBLES;
-    hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<HYPER>), dim3((unsigned)total), dim3(64), lds, st, a);
+    const size_t N = (size_t)a.N, D = 40, DD = 1600;
+    for (int p0 = 0; p0 < a.P; p0 += MAXP) {
+        EsdeArgs s = a;
+        s.P = a.P - p0 < MAXP ? a.P - p0 : MAXP;
+        const size_t o = (size_t)p0 * N;
+        s.A += o * DD; s.b += o * D; s.m += o * D; s.S += o * DD;
+        s.sig_inv_diag += (size_t)p0 * a.sig_stride;
+        s.theta += (size_t)p0 * a.theta_stride;
+        s.Esde_t += o; s.Ef += o * D; s.dEdm += o * D; s.dEdS += o * DD;
+        if (s.Edf) s.Edf += o * DD;
+        if (s.dth_t) s.dth_t += o * D;
+        if (s.dSig_t) s.dSig_t += o * D;
+        if (s.status) s.status += o;
+        const dim3 grid((unsigned)s.N, (unsigned)s.P);
+        if (s.dSig_t) hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<true>, grid, dim3(64), lds, st, s);
+        else hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<false>, grid, dim3(64), lds, st, s);
+    }
 }
 
 template <int D>
 void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
-    static const bool use_wave = getenv("VGPA_L96_TILED") == nullptr;
-    if (D == 40 && use_wave) {
-        if (a.dSig_t) launch_l96_wave40<true>(a, total, st);
-        else launch_l96_wave40<false>(a, total, st);
-    } else if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
+    if constexpr (D == 40) launch_l96_wave40(a, st);
+    else if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
     else launch_l96_tiled_h<D, false>(a, total, st);
     if (a.status) {
-        // steps the tiled kernel flagged as not positive definite
+        // steps the energy kernel flagged as not positive definite
         const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 5 * D);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_fixup_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

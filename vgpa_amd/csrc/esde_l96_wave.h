@@ -45,14 +45,22 @@
 
 typedef double wv_f64x4 __attribute__((ext_vector_type(4)));
 
+#ifdef VGPA_STAMPS
+#define WV_STAMP(k) do { if (blockIdx.x == 1000 && blockIdx.y == 30 && threadIdx.x == 0) g_l96_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WV_STAMP(k) do { } while (0)
+#endif
+
 struct L96Wave {
     static constexpr int D = 40, LD = 42, MS = D * LD, DD = D * D;
     static constexpr int XLD = 18;                       // scratch tile
     static constexpr int OFF_X = MS;
-    static constexpr int OFF_PROW = OFF_X + 16 * XLD;    // pivot row of S and of M
-    static constexpr int OFF_VEC = OFF_PROW + 32;
+    static constexpr int OFF_VEC = OFF_X + 16 * XLD;
     static constexpr int VL = 48;                        // vectors: m, A m - b, Sigma^-1, u, sa, sb
-    static constexpr int LDS_DOUBLES = OFF_VEC + 6 * VL;
+    // Stores of lanes whose row or column does not exist go to a per-lane slot here (an
+    // address select instead of an exec-mask region); a slot takes the four rows of a tile.
+    static constexpr int OFF_DUMP = OFF_VEC + 6 * VL;
+    static constexpr int LDS_DOUBLES = OFF_DUMP + 64 + 3 * LD;     // >= 128: two doubles per lane as well
 };
 
 __device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
@@ -83,17 +91,80 @@ __device__ __forceinline__ double wv_col_sum(double v) {
     return wv_mfma(1.0, v, z)[0];
 }
 
+// v_mov_b64 / v_fmac_f64 with the DPP control row_newbcast:N take their first source from
+// lane N of the reading lane's own row of 16.  The two wait states a DPP read needs after
+// the vector ALU wrote its source are supplied here (s_nop 1): the compiler does not look
+// into inline assembly.
+template <int N>
+__device__ __forceinline__ double wv_row_bcast(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
+    return r;
+}
+// acc += (t of lane N of the row) * x
+template <int N, bool NOP>
+__device__ __forceinline__ void wv_fmac_bcast(double& acc, double t, double x) {
+    if (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(t), "v"(x), "n"(N));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(t), "v"(x), "n"(N));
+}
+// rows 1 and 3 of the result are rows 0 and 2 of v; rows 0 and 2 are unchanged
+__device__ __forceinline__ double wv_even_rows_to_odd(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int rlo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[0];
+    const int rhi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false)[0];
+    return __hiloint2double(rhi, rlo);
+}
+
+template <int K, int I, int NP>
+struct WvElim {
+    static __device__ __forceinline__ void run(double (&x)[NP], double ntk) {
+        if constexpr (I < NP) {
+            wv_fmac_bcast<I, I == K + 1>(x[I], ntk, x[K]);
+            WvElim<K, I + 1, NP>::run(x, ntk);
+        }
+    }
+};
+template <int K, int NP>
+struct WvPivots {
+    static __device__ __forceinline__ void run(double (&x)[NP], int c, double& pmin, double& pivc) {
+        if constexpr (K < NP) {
+            const double piv = wv_row_bcast<K>(x[K]);           // S rows: S[k][k]; M rows: 1
+            pmin = fmin(pmin, piv);
+            pivc = (c == K) ? piv : pivc;
+            // multipliers -S[k][i] / S[k][k] in lane i of the S rows, copied to the M rows
+            const double ntk = wv_even_rows_to_odd(x[K] * -rcp_refined(piv));
+            WvElim<K, K + 1, NP>::run(x, ntk);
+            WvPivots<K + 1, NP>::run(x, c, pmin, pivc);
+        }
+    }
+};
+template <int I, int NP>
+struct WvScale {
+    static __device__ __forceinline__ void run(double (&x)[NP], double rsc) {
+        if constexpr (I < NP) {
+            x[I] *= wv_row_bcast<I>(rsc);
+            WvScale<I + 1, NP>::run(x, rsc);
+        }
+    }
+};
+
 // One 16-wide diagonal block of the factorisation (NP valid rows: 16, or 8 for the last).
 // In: the block of the partly updated S in buf.  Out: L_JJ in the lower triangle of the
 // block; T_J = L_JJ^-1 transposed and shifted two columns right in its upper triangle.
-// Lane c < 16 holds column c of the block, lane 16 + c column c of M, the accumulated row
-// operations (M = I at the start).  Per pivot k: the pivot S[k][k] and the multipliers
-// t_i = S[k][i] / S[k][k] are read across lanes into scalar registers, and every lane
-// eliminates its column: x[i] -= t_i x[k].  That leaves U = D L~' in the S lanes and
-// M = L~^-1 in the M lanes (S = L~ D L~'), so L = U' D^-1/2 and T = D^-1/2 M: both are
-// x[i] / sqrt(d_i).  No LDS traffic inside the pivot chain.  Returns false on a pivot <= 0.
+// Lane c of row 0 (of 16 lanes) holds column c of the block, lane c of row 1 column c of M,
+// the accumulated row operations (M = I at the start); rows 2 and 3 repeat rows 0 and 1.
+// Per pivot k every lane eliminates its column, x[i] -= t_i x[k], with the multipliers
+// t_i = S[k][i] / S[k][k] taken by DPP broadcast from lane i of the S row.  That leaves
+// U = D L~' in the S lanes and M = L~^-1 in the M lanes (S = L~ D L~'), so L = U' D^-1/2 and
+// T = D^-1/2 M: both are x[i] / sqrt(d_i).  No LDS traffic and no scalar registers inside
+// the pivot chain.  Returns false on a pivot <= 0 (a NaN pivot is not flagged: it poisons the
+// outputs of the step instead).
 template <int J>
-__device__ __forceinline__ bool wv_factor_diag(double* buf, int lane) {
+__device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, int lane) {
     constexpr int LD = L96Wave::LD, c0 = 16 * J, NP = (J == 2) ? 8 : 16;
     const int c = lane & 15;
     const bool is_m = (lane & 16) != 0;
@@ -109,32 +180,32 @@ __device__ __forceinline__ bool wv_factor_diag(double* buf, int lane) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) x[i] = is_m ? ((i == c) ? 1.0 : 0.0) : x[i];
     }
-    bool ok = true;
-    double pivc = 1.0;             // pivot of row c
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const double piv = readlane_f64(x[k], k);
-        ok = ok && (piv > 0.0);
-        pivc = (c == k) ? piv : pivc;
-        const double tk = x[k] * rcp_refined(piv);
-#pragma unroll
-        for (int i = k + 1; i < NP; ++i) x[i] = fma(-readlane_f64(tk, i), x[k], x[i]);
-    }
-    const double rsc = rsqrt_refined(pivc);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) x[i] *= readlane_f64(rsc, i);
+    double pmin = 1.0;             // smallest pivot so far (a running minimum keeps no pivot alive)
+    double pivc = 1.0;             // pivot of row c (S rows)
+    WvPivots<0, NP>::run(x, c, pmin, pivc);
+    const double rsc = wv_even_rows_to_odd(rsqrt_refined(pivc));
+    WvScale<0, NP>::run(x, rsc);
     // S lane c: L[c][k] = x[k] for k <= c, to buf[c0 + c][c0 + k]
     // M lane c: T[i][c] = x[i] for i >= c, to buf[c0 + c][c0 + i + 2]
-    if (lane < 32 && c < NP) {
+    {
+        const bool lane_writes = lane < 32 && c < NP;
         double* dst = buf + (c0 + c) * LD + c0 + (is_m ? 2 : 0);
+        double* nowhere = dump + 2 * lane;
 #pragma unroll
         for (int h = 0; h < NP / 2; ++h) {
-            const bool wr = is_m ? (2 * h + 1 >= c) : (2 * h <= c);
-            if (wr) *reinterpret_cast<double2*>(dst + 2 * h) = make_double2(x[2 * h], x[2 * h + 1]);
+            const bool wr = lane_writes && (is_m ? (2 * h + 1 >= c) : (2 * h <= c));
+            *reinterpret_cast<double2*>(wr ? dst + 2 * h : nowhere) = make_double2(x[2 * h], x[2 * h + 1]);
         }
     }
     wave_lds_fence();
-    return ok;
+    return __builtin_amdgcn_ballot_w64(!(pmin > 0.0)) == 0;
+}
+
+// indices l + 1, l - 1, l - 2 on the ring of D = 40 components
+__device__ __forceinline__ void wv_ring(int l, int& f1, int& b1, int& b2) {
+    f1 = (l == L96Wave::D - 1) ? 0 : l + 1;
+    b1 = (l == 0) ? L96Wave::D - 1 : l - 1;
+    b2 = (l <= 1) ? l + L96Wave::D - 2 : l - 2;
 }
 
 template <bool HYPER>
@@ -150,36 +221,53 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double* uv = sIv + VL;
     double* sav = uv + VL;      // sqrt|g|
     double* sbv = sav + VL;     // sign(g) sqrt|g|
-    const int lane = threadIdx.x;
-    const int c16 = lane & 15, g4 = lane >> 4;
-    const int pi = 4 * (c16 & 3) + (c16 >> 2);     // matrix row (within a tile) this lane feeds in as operand row c16
-    const size_t e = blockIdx.x;                   // p * N + t
-    const int p = (int)(e / a.N);
+    double* dump = lds + C::OFF_DUMP;
+    const int lane0 = threadIdx.x;
+    constexpr int NQ = (DD / 2 + 63) / 64;         // 13 sixteen-byte pieces of S(t) per lane
+    const int p = blockIdx.y;                      // problem, step: no division by N
+    const size_t e = (size_t)p * a.N + blockIdx.x;
+    // The lane index is made opaque again at every phase: addresses and masks derived from it
+    // are then recomputed where they are used instead of being kept in registers (or spilled)
+    // from one phase to the next.
+    int lane = lane0, c16, g4, pi;
+#define WV_RELANE()                                                                  \
+    do {                                                                             \
+        asm volatile("" : "+v"(lane));                                               \
+        c16 = lane & 15;                                                             \
+        g4 = lane >> 4;                                                              \
+        pi = 4 * (c16 & 3) + (c16 >> 2); /* matrix row fed in as operand row c16 */  \
+    } while (0)
+    WV_RELANE();
     const double theta = a.theta[(size_t)p * a.theta_stride];
 
-    VGPA_STAMP(16);
-    // ---- phase 1: loads ---------------------------------------------------------------
-    const int lv = min(lane, D - 1);
-    const double m_l = a.m[e * D + lv];
-    const double b_l = a.b[e * D + lv];
-    const double si_l = a.sig_inv_diag[(size_t)p * a.sig_stride + lv];
-    constexpr int NQ = (DD / 2 + 63) / 64;         // 13 sixteen-byte pieces per lane
+    WV_STAMP(16);
+    // ---- phase 1: loads; S(t) goes to LDS ----------------------------------------------------
+    double sx[NQ], sy[NQ];
     {
         const double2* Sg = reinterpret_cast<const double2*>(a.S + e * DD);
-        double sx[NQ], sy[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const double2 v = Sg[min(i * 64 + lane, DD / 2 - 1)];
             sx[i] = v.x;
             sy[i] = v.y;
         }
+    }
+    {
+        // piece q = 64 i + lane is row q / 20, column pair q % 20; 64 = 3 * 20 + 4
+        int row = (lane >= 20) + (lane >= 40) + (lane >= 60), cp = lane - 20 * row;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = i * 64 + lane;
-            if (q < DD / 2)
-                *reinterpret_cast<double2*>(buf + ((2 * q) / D) * LD + ((2 * q) % D)) = make_double2(sx[i], sy[i]);
+            double* dst = (i < NQ - 1 || lane < DD / 2 - 64 * (NQ - 1)) ? buf + row * LD + 2 * cp : dump + 2 * lane;
+            *reinterpret_cast<double2*>(dst) = make_double2(sx[i], sy[i]);
+            cp += 4;
+            row += 3 + (cp >= 20 ? 1 : 0);
+            cp -= (cp >= 20 ? 20 : 0);
         }
     }
+    const int lv = min(lane, D - 1);
+    const double m_l = a.m[e * D + lv];
+    const double b_l = a.b[e * D + lv];
+    const double si_l = a.sig_inv_diag[(size_t)p * a.sig_stride + lv];
     double af[3][10];                              // A[16 i + pi][4 s + g4]
     {
         const double* Ae = a.A + e * DD;
@@ -201,12 +289,13 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double Cxx = 0.0;
     {
         const int l = lv;
-        const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
+        int f1, b1, b2;
+        wv_ring(l, f1, b1, b2);
         Cxx = buf[f1 * LD + b1] - buf[b2 * LD + b1];
     }
     wave_lds_fence();
 
-    VGPA_STAMP(17);
+    WV_STAMP(17);
     // ---- phase 2: blocked Cholesky ------------------------------------------------------
     // Operand fetchers.  "rows" operands: element [r][k] of a block whose rows are matrix
     // rows; as A operand the lane feeds row pi, as B operand (the block transposed) row c16.
@@ -228,14 +317,24 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) t[q] = buf[min(16 * I + 4 * g4 + q, D - 1) * LD + 16 * K + c16];
     };
-    auto tile_wr = [&](int I, int K, const wv_f64x4& t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = 16 * I + 4 * g4 + q;
-            if (row < D && 16 * K + c16 < D) buf[row * LD + 16 * K + c16] = t[q];
-        }
+    // rows 16 I + 4 g4 + q, column 16 K + c16 of buf; lanes outside the 40 x 40 matrix (only
+    // in block row / column 2) write to their dump slot
+    auto tile_ptr = [&](int I, int K) {
+        const bool valid = (I < 2 || g4 < 2) && (K < 2 || c16 < 8);
+        return valid ? buf + (16 * I + 4 * g4) * LD + 16 * K + c16 : dump + lane;
     };
-    bool ok = wv_factor_diag<0>(buf, lane);
+    auto tile_wr = [&](int I, int K, const wv_f64x4& t) {
+        double* dst = tile_ptr(I, K);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * LD] = t[q];
+    };
+    auto tile_zero = [&](int I, int K) {
+        double* dst = tile_ptr(I, K);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * LD] = 0.0;
+    };
+    bool ok = wv_factor_diag<0>(buf, dump, lane);
+    WV_STAMP(27);
     {
         // block column 0: panel L_10, L_20 = S_I0 T_0'
         double t0[4], s10[4], s20[4];
@@ -272,7 +371,10 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         tile_wr(2, 1, s21);
         wave_lds_fence();
     }
-    ok = wv_factor_diag<1>(buf, lane) && ok;
+    WV_STAMP(28);
+    WV_RELANE();
+    ok = wv_factor_diag<1>(buf, dump, lane) && ok;
+    WV_STAMP(29);
     {
         // block column 1: panel L_21 = S_21 T_1'
         double t1[4], s21[4];
@@ -304,9 +406,12 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         tile_wr(2, 2, s22);
         wave_lds_fence();
     }
-    ok = wv_factor_diag<2>(buf, lane) && ok;
+    WV_STAMP(30);
+    WV_RELANE();
+    ok = wv_factor_diag<2>(buf, dump, lane) && ok;
 
-    VGPA_STAMP(18);
+    WV_STAMP(18);
+    WV_RELANE();
     // ---- phase 3: <f>, A m - b, optionally the dense <df/dx> ------------------------------
     {
         double mk[10];
@@ -328,7 +433,8 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double a0 = 0.0;          // squared centre-point residual of component `lane`
     {
         const int l = lv;
-        const int f1 = (l + 1) % D, b1 = (l + D - 1) % D, b2 = (l + D - 2) % D;
+        int f1, b1, b2;
+        wv_ring(l, f1, b1, b2);
         const double base = basev[l] - b_l;
         const double f0 = (mv[f1] - mv[b2]) * mv[b1] - m_l + theta;   // drift at the mean
         const double Ef = Cxx + f0;
@@ -374,36 +480,36 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         return;
     }
 
-    VGPA_STAMP(19);
+    WV_STAMP(19);
     const double kappa = 1.05 * D;
     const double c2 = D + kappa;
     const double cs = sqrt(c2);
     const double w0 = kappa / c2, w1 = 1.0 / (2.0 * c2);
 
+    WV_RELANE();
     // ---- phase 4: G = A L, then the sigma-point residuals ---------------------------------
-    double vp[3] = {0.0, 0.0, 0.0}, vm[3] = {0.0, 0.0, 0.0};
+    // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
+    // sigma-point pair 16 j + c16, summed over this lane's state indices
+    double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
     double mb[3][4] = {};
     {
-        wv_f64x4 G[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) G[i][j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int col = 16 * j + c16;
-#pragma unroll
-            for (int s = 4 * j; s < 10; ++s) {
-                const int k = 4 * s + g4;
-                double v = buf[k * LD + col];
-                if (s < 4 * j + 4) v = (k >= col) ? v : 0.0;     // diagonal block: only the lower triangle is L
-#pragma unroll
-                for (int i = 0; i < 3; ++i) G[i][j] = wv_mfma(af[i][s], v, G[i][j]);
-            }
-        }
-    VGPA_STAMP(20);
+        // one tile row of G at a time (the three tiles of a row share the A fragments, and
+        // only 24 result registers are alive at once)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+            wv_f64x4 G[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                G[j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
+                const int col = 16 * j + c16;
+#pragma unroll
+                for (int s = 4 * j; s < 10; ++s) {
+                    const int k = 4 * s + g4;
+                    double v = buf[k * LD + col];
+                    if (s < 4 * j + 4) v = (k >= col) ? v : 0.0;     // diagonal block: only the lower triangle is L
+                    G[j] = wv_mfma(af[i][s], v, G[j]);
+                }
+            }
             const int d0r = 16 * i + 4 * g4;
             const bool rows_valid = d0r < D;
             const int d0 = rows_valid ? d0r : D - 4;
@@ -411,13 +517,18 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
             double mm[7];
 #pragma unroll
             for (int w = 0; w < 7; ++w) {
-                rw[w] = (d0 + D - 2 + w) % D;
+                const int r = d0 - 2 + w;            // in [-2, 40]: wraps at most once
+                rw[w] = r < 0 ? r + D : (r >= D ? r - D : r);
                 mm[w] = mv[rw[w]];
             }
-            double bs[4], si[4];
+            // per state index d = d0 + q (position q + 2 of the window): the drift at the mean
+            // plus A m - b, and the two mean factors of the quadratic term
+            double kq[4], aq[4], bq[4], si[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bs[q] = basev[d0 + q];
+                aq[q] = mm[q + 3] - mm[q];
+                bq[q] = mm[q + 1];
+                kq[q] = fma(aq[q], bq[q], theta - mm[q + 2]) + basev[d0 + q];
                 si[q] = rows_valid ? sIv[d0 + q] : 0.0;
             }
 #pragma unroll
@@ -433,35 +544,33 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    // state index d = d0 + q sits at position q + 2 of the 7-row window
-                    const double xm2p = mm[q] + o[q], xm1p = mm[q + 1] + o[q + 1];
-                    const double x0p = mm[q + 2] + o[q + 2], xp1p = mm[q + 3] + o[q + 3];
-                    const double xm2m = mm[q] - o[q], xm1m = mm[q + 1] - o[q + 1];
-                    const double x0m = mm[q + 2] - o[q + 2], xp1m = mm[q + 3] - o[q + 3];
-                    const double fp = (xp1p - xm2p) * xm1p - x0p + theta;
-                    const double fm = (xp1m - xm2m) * xm1m - x0m + theta;
-                    const double cG = cs * G[i][j][q];
-                    const double rp = fp + bs[q] + cG, rm = fm + bs[q] - cG;
-                    const double rp2 = rp * rp, rm2 = rm * rm;
-                    vp[j] = fma(si[q], rp2, vp[j]);
-                    vm[j] = fma(si[q], rm2, vm[j]);
-                    if (HYPER) mb[i][q] += col_valid ? w1 * (rp2 + rm2) : 0.0;
+                    // With x+- = m +- o the residuals of the two sigma points are
+                    //   r+- = (a +- de)(b +- ep) - (m0 +- o0) + theta + base +- c G
+                    // so  (r+ + r-)/2 = k + de ep   and   (r+ - r-)/2 = a ep + de b - o0 + c G.
+                    const double de = o[q + 3] - o[q], ep = o[q + 1];
+                    const double sp = fma(de, ep, kq[q]);
+                    const double dp = fma(aq[q], ep, fma(de, bq[q], fma(cs, G[j][q], -o[q + 2])));
+                    const double t = fma(dp, dp, sp * sp);             // (r+^2 + r-^2) / 2
+                    hp[j] = fma(si[q], t, hp[j]);
+                    hq[j] = fma(si[q] * sp, dp, hq[j]);                // (r+^2 - r-^2) / 4
+                    if (HYPER) mb[i][q] += col_valid ? 2.0 * w1 * t : 0.0;
                 }
             }
         }
     }
-    VGPA_STAMP(21);
+    WV_STAMP(21);
+    WV_RELANE();
     // ---- phase 5: Esde(t), u, g ------------------------------------------------------------
     {
         double tot = 0.0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            vp[j] = wv_col_sum(vp[j]);
-            vm[j] = wv_col_sum(vm[j]);
-            tot += (16 * j + c16 < D) ? vp[j] + vm[j] : 0.0;
+            hp[j] = wv_col_sum(hp[j]);
+            hq[j] = wv_col_sum(hq[j]);
+            tot += (16 * j + c16 < D) ? hp[j] : 0.0;
         }
-        // centre point: component l = lane < 40; sum over the lane groups, then over the row
-        tot = readlane_f64(wv_row_sum(tot), 0);
+        // sum over the sigma-point pairs, v+ + v- = 2 hp; the centre point: component l = lane
+        tot = 2.0 * readlane_f64(wv_row_sum(tot), 0);
         const double v0 = readlane_f64(wv_row_sum(wv_col_sum(lane < D ? si_l * a0 : 0.0)), 0);
         const double Esde = 0.5 * (w0 * v0 + w1 * tot);
         if (g4 == 0) {
@@ -469,9 +578,9 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
             for (int j = 0; j < 3; ++j) {
                 const int col = 16 * j + c16;
                 if (col < D) {
-                    const double gk = 0.125 * (vp[j] + vm[j]) - 0.5 * Esde;
+                    const double gk = 0.25 * hp[j] - 0.5 * Esde;       // (v+ + v-)/8 - Esde/2
                     const double sq = sqrt(fabs(gk));
-                    uv[col] = vp[j] - vm[j];
+                    uv[col] = 4.0 * hq[j];                            // v+ - v-
                     sav[col] = sq;
                     sbv[col] = copysign(sq, gk);
                 }
@@ -504,7 +613,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     }
     wave_lds_fence();
 
-    VGPA_STAMP(22);
+    WV_STAMP(22);
     // ---- phase 6: W = L^-1 in place ---------------------------------------------------------
     //   W_10 = -T_1 (L_10 T_0)     W_21 = -T_2 (L_21 T_1)     W_20 = -T_2 (L_20 T_0 + L_21 W_10)
     {
@@ -582,7 +691,8 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         for (int s = 0; s < 2; ++s) w20 = wv_mfma(nt2[s], xb[s], w20);
         wave_lds_fence();
         tile_wr(2, 0, w20);
-        // diagonal blocks: W_JJ = T_J, from the shifted upper triangle to its place
+        // diagonal blocks: W_JJ = T_J, from the shifted upper triangle to its place; everything
+        // above the diagonal of W becomes zero, so that the products below need no masks
         const int ra = lane >> 2, cb = 4 * (lane & 3);
         double t[3][4];
 #pragma unroll
@@ -595,68 +705,82 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
             }
         wave_lds_fence();
 #pragma unroll
-        for (int J = 0; J < 3; ++J)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int b = cb + q;
-                if ((b <= ra) && (J < 2 || ra < 8)) buf[(16 * J + ra) * LD + 16 * J + b] = t[J][q];
-            }
+        for (int J = 0; J < 2; ++J) {
+            double* dst = buf + (16 * J + ra) * LD + 16 * J + cb;
+            *reinterpret_cast<double2*>(dst) = make_double2(t[J][0], t[J][1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(t[J][2], t[J][3]);
+        }
+        {
+            double* dst = (ra < 8 && cb < 8) ? buf + (32 + ra) * LD + 32 + cb : dump + 2 * lane;
+            *reinterpret_cast<double2*>(dst) = make_double2(t[2][0], t[2][1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(t[2][2], t[2][3]);
+        }
+        tile_zero(0, 1);
+        tile_zero(0, 2);
+        tile_zero(1, 2);
     }
     wave_lds_fence();
 
-    VGPA_STAMP(23);
-    // ---- phase 7: dEsde/dm and dEsde/dS -------------------------------------------------------
+    WV_STAMP(23);
+    WV_STAMP(24);
+    WV_RELANE();
+    // ---- phase 7: dEsde/dm = (w c / 2) W' u and dEsde/dS = W' diag(g) W ----------------------
+    // One pass over the rows k of W.  Columns 40..47 of a row are whatever follows in LDS
+    // (finite numbers): they only reach the padded rows / columns of the results.
     {
-        const int l = lv;
-        double y0 = 0.0, y1 = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < D; k += 2) {
-            const double2 u2 = *reinterpret_cast<const double2*>(uv + k);
-            const double w0k = buf[k * LD + l], w1k = buf[(k + 1) * LD + l];
-            y0 = fma(k >= l ? w0k : 0.0, u2.x, y0);
-            y1 = fma(k + 1 >= l ? w1k : 0.0, u2.y, y1);
-        }
-        if (lane < D) a.dEdm[e * D + l] = 0.5 * w1 * cs * (y0 + y1);
-    }
-    VGPA_STAMP(24);
-    {
-        wv_f64x4 acc[3][3];
+        wv_f64x4 acc[3][3], ym[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) {
+            ym[i] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
+        }
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             const int k = 4 * s + g4;
             const double sa = sav[k], sb = sbv[k];
-            const int nt = s / 4 + 1;                // column blocks 0 .. nt-1 reach row k
-            double ao[3], bo[3];
+            const double ub = (c16 == 0) ? uv[k] : 0.0;      // u as column 0 of a B operand
+            const int nt = s / 4 + 1;                        // column blocks 0 .. nt-1 reach row k
+            double wa[3], ao[3], bo[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 if (t < nt) {
-                    const int ca = 16 * t + pi, cb = 16 * t + c16;
-                    const double wa = buf[k * LD + ca], wb = buf[k * LD + cb];
-                    ao[t] = (k >= ca && ca < D) ? sa * wa : 0.0;
-                    bo[t] = (k >= cb && cb < D) ? sb * wb : 0.0;
+                    wa[t] = buf[k * LD + 16 * t + pi];
+                    ao[t] = sa * wa[t];
+                    bo[t] = sb * buf[k * LD + 16 * t + c16];
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i) {
+                if (i < nt) ym[i] = wv_mfma(wa[i], ub, ym[i]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     if (i < nt && j < nt) acc[i][j] = wv_mfma(ao[i], bo[j], acc[i][j]);
+            }
         }
-    VGPA_STAMP(25);
+        // (W' u)[16 i + 4 g4 + q] sits in register q of the lanes with c16 == 0
+        wave_lds_fence();
+        if (c16 == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) basev[16 * i + 4 * g4 + q] = ym[i][q];
+        }
+        wave_lds_fence();
+        if (lane < D) a.dEdm[e * D + lane] = 0.5 * w1 * cs * basev[lane];
+    WV_STAMP(25);
         double* Gd = a.dEdS + e * DD;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j) {
+                if ((i < 2 || g4 < 2) && (j < 2 || c16 < 8)) {
+                    double* dst = Gd + (16 * i + 4 * g4) * D + 16 * j + c16;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = 16 * i + 4 * g4 + q, col = 16 * j + c16;
-                    if (row < D && col < D) Gd[row * D + col] = acc[i][j][q];
+                    for (int q = 0; q < 4; ++q) dst[q * D] = acc[i][j][q];
                 }
+            }
     }
-    VGPA_STAMP(26);
+    WV_STAMP(26);
+#undef WV_RELANE
 }
