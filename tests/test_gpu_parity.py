@@ -313,6 +313,44 @@ def test_lorenz96_energy_kernels_vs_oracle(D):
     assert np.array_equal(out[4], np.swapaxes(out[4], 1, 2)) or D not in (16, 40)
 
 
+def test_lorenz96_d40_more_problems_than_one_grid_dimension():
+    """The D = 40 energy kernel takes a (steps x problems) grid; more than 65535 problems are
+    launched in slices of the problem axis.  Problems on both sides of the slice boundary must
+    give the bits a small batch gives (N = 1 keeps the arrays at 0.84 GB each)."""
+    import torch
+    from vgpa_amd import engine, _lib
+    D, N, P = 40, 1, 65535 + 5
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    dev = torch.device("cuda", 0)
+    rnd = lambda *shape: torch.randn(shape, dtype=torch.float64, device=dev, generator=gen)   # noqa: E731
+    picks = [0, 1, 65534, 65535, 65536, P - 1]
+    A = 6.0 * torch.eye(D, dtype=torch.float64, device=dev).expand(P, N, D, D).contiguous()
+    A[picks] += rnd(len(picks), N, D, D)
+    b, m = 4.0 * rnd(P, N, D), 3.0 * rnd(P, N, D)
+    S = 0.5 * torch.eye(D, dtype=torch.float64, device=dev).expand(P, N, D, D).contiguous()
+    X = rnd(len(picks), N, D, D)
+    S[picks] += X @ X.transpose(-1, -2) / D
+    sig = 1.0 + torch.rand((P, D), dtype=torch.float64, device=dev, generator=gen)
+    theta = 7.0 + torch.rand((P, 1), dtype=torch.float64, device=dev, generator=gen)
+    big = engine.esde(_lib.SYS_L96_UT, A, b, m, S, sig, theta, want_edf=False, want_hyper=True)
+    ix = torch.tensor(picks, device=dev)
+    small = engine.esde(_lib.SYS_L96_UT, A[ix].contiguous(), b[ix].contiguous(), m[ix].contiguous(),
+                        S[ix].contiguous(), sig[ix].contiguous(), theta[ix].contiguous(), want_edf=False,
+                        want_hyper=True)
+    assert int(big["status"].max().item()) == 0
+    for k in ("Esde_t", "Ef", "dEdm", "dEdS", "dth_t", "dSig_t"):
+        assert torch.equal(big[k][ix], small[k]), k
+    # and the small batch is right: one problem against the oracle
+    from vgpa_amd.dynamics import sys_lorenz_96_ut  # noqa: F401
+    j = 3
+    sde = dict(N=N, D=D, dt=0.01, Sig=np.diag(1.0 / sig[picks[j]].cpu().numpy()), theta=float(theta[picks[j]].item()),
+               obsX=np.array([0]))
+    ref = orc.energy_mode("l96_ut", A[picks[j]].cpu().numpy(), b[picks[j]].cpu().numpy(), m[picks[j]].cpu().numpy(),
+                          S[picks[j]].cpu().numpy(), sde)
+    assert relerr(small["dEdS"][j].cpu().numpy(), ref[4]) <= TOL
+    assert relerr(small["dEdm"][j].cpu().numpy(), ref[3]) <= TOL
+
+
 @pytest.mark.parametrize("D", [6, 16, 40])
 @pytest.mark.parametrize("method", METHODS)
 def test_symmetric_scan_kernels_are_bitwise_the_general_ones(D, method):

@@ -12,7 +12,7 @@ from vgpa_amd import engine
 import bench
 dev = torch.device("cuda", 0)
 WANT_EDF = '--edf' in sys.argv
-D, N, dt, P = 40, 2002, 0.005, 64
+D, N, dt, P = 16, 2002, 0.005, 64   # the workgroup-per-step kernel runs D = 16 (D = 40: l96_wave_stamps.py)
 A, b, sde, m0, S0, thetas = bench.synth_problem(D, N, dt, P, 1, dev)
 prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
 m, S = engine.fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=True)
