@@ -56,11 +56,12 @@ struct L96Wave {
     static constexpr int XLD = 18;                       // scratch tile
     static constexpr int OFF_X = MS;
     static constexpr int OFF_VEC = OFF_X + 16 * XLD;
-    static constexpr int VL = 48;                        // vectors: m, A m - b, Sigma^-1, u, sa, sb
+    static constexpr int VL = 48;                        // vectors: m, A m - b, Sigma^-1, u, sa, sb, m on the ring
     // Stores of lanes whose row or column does not exist go to a per-lane slot here (an
     // address select instead of an exec-mask region); a slot takes the four rows of a tile.
-    static constexpr int OFF_DUMP = OFF_VEC + 6 * VL;
-    static constexpr int LDS_DOUBLES = OFF_DUMP + 64 + 3 * LD;     // >= 128: two doubles per lane as well
+    static constexpr int OFF_DUMP = OFF_VEC + 7 * VL;
+    static constexpr int OFF_ZERO = OFF_DUMP + 64 + 3 * LD;        // dump >= 128: two doubles per lane as well
+    static constexpr int LDS_DOUBLES = OFF_ZERO + 2;               // one 0.0: what a masked operand load reads
 };
 
 __device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
@@ -221,7 +222,9 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double* uv = sIv + VL;
     double* sav = uv + VL;      // sqrt|g|
     double* sbv = sav + VL;     // sign(g) sqrt|g|
+    double* mvx = sbv + VL;     // mvx[k] = m[(k - 2) mod 40], k = 0 .. 47: stencil windows need no wrap
     double* dump = lds + C::OFF_DUMP;
+    const double* zslot = lds + C::OFF_ZERO;       // holds 0.0: masked loads select this address
     const int lane0 = threadIdx.x;
     constexpr int NQ = (DD / 2 + 63) / 64;         // 13 sixteen-byte pieces of S(t) per lane
     const int p = blockIdx.y;                      // problem, step: no division by N
@@ -240,8 +243,14 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     WV_RELANE();
     const double theta = a.theta[(size_t)p * a.theta_stride];
 
+    const double kappa = 1.05 * D;
+    const double c2 = D + kappa;                   // the sigma points are m +- sqrt(c2) L[:, i]
+    const double w0 = kappa / c2, w1 = 1.0 / (2.0 * c2);
+
     WV_STAMP(16);
-    // ---- phase 1: loads; S(t) goes to LDS ----------------------------------------------------
+    // ---- phase 1: loads; c2 S(t) goes to LDS -------------------------------------------------
+    // Everything below works with L' = chol(c2 S) = sqrt(c2) L, the sigma-point offsets
+    // themselves, and W' = L'^-1 = W / sqrt(c2); the factors c2 are put back at the outputs.
     double sx[NQ], sy[NQ];
     {
         const double2* Sg = reinterpret_cast<const double2*>(a.S + e * DD);
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             double* dst = (i < NQ - 1 || lane < DD / 2 - 64 * (NQ - 1)) ? buf + row * LD + 2 * cp : dump + 2 * lane;
-            *reinterpret_cast<double2*>(dst) = make_double2(sx[i], sy[i]);
+            *reinterpret_cast<double2*>(dst) = make_double2(c2 * sx[i], c2 * sy[i]);
             cp += 4;
             row += 3 + (cp >= 20 ? 1 : 0);
             cp -= (cp >= 20 ? 20 : 0);
@@ -279,10 +288,12 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         }
     }
     if (lane < VL) {
+        mvx[lane] = a.m[e * D + (lane < 2 ? lane + D - 2 : (lane < D + 2 ? lane - 2 : lane - D - 2))];
         mv[lane] = lane < D ? m_l : 0.0;
         sIv[lane] = lane < D ? si_l : 0.0;
         basev[lane] = 0.0;
     }
+    if (lane < 2) lds[C::OFF_ZERO + lane] = 0.0;
     wave_lds_fence();
 
     // the covariance term of <f>, before S is overwritten by its factor
@@ -291,7 +302,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         const int l = lv;
         int f1, b1, b2;
         wv_ring(l, f1, b1, b2);
-        Cxx = buf[f1 * LD + b1] - buf[b2 * LD + b1];
+        Cxx = (buf[f1 * LD + b1] - buf[b2 * LD + b1]) * (1.0 / c2);
     }
     wave_lds_fence();
 
@@ -309,8 +320,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 4 * s + g4;
-            const double v = buf[(16 * J + k) * LD + 16 * J + c16 + 2];
-            o[s] = (k <= c16) ? v : 0.0;
+            o[s] = *((k <= c16) ? buf + (16 * J + k) * LD + 16 * J + c16 + 2 : zslot);
         }
     };
     auto tile_rd = [&](int I, int K, wv_f64x4& t) {
@@ -481,10 +491,6 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     }
 
     WV_STAMP(19);
-    const double kappa = 1.05 * D;
-    const double c2 = D + kappa;
-    const double cs = sqrt(c2);
-    const double w0 = kappa / c2, w1 = 1.0 / (2.0 * c2);
 
     WV_RELANE();
     // ---- phase 4: G = A L, then the sigma-point residuals ---------------------------------
@@ -505,22 +511,29 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
                 for (int s = 4 * j; s < 10; ++s) {
                     const int k = 4 * s + g4;
-                    double v = buf[k * LD + col];
-                    if (s < 4 * j + 4) v = (k >= col) ? v : 0.0;     // diagonal block: only the lower triangle is L
-                    G[j] = wv_mfma(af[i][s], v, G[j]);
+                    // diagonal block: only the lower triangle is L'
+                    const double* src = (s < 4 * j + 4 && k < col) ? zslot : buf + k * LD + col;
+                    G[j] = wv_mfma(af[i][s], *src, G[j]);
                 }
             }
             const int d0r = 16 * i + 4 * g4;
             const bool rows_valid = d0r < D;
             const int d0 = rows_valid ? d0r : D - 4;
+            // window rows d0 - 2 .. d0 + 4 on the ring: only the first lane group of tile row 0
+            // (rows -2, -1) and the lanes with d0 = 36 (row 40) wrap
             int rw[7];
             double mm[7];
 #pragma unroll
             for (int w = 0; w < 7; ++w) {
-                const int r = d0 - 2 + w;            // in [-2, 40]: wraps at most once
-                rw[w] = r < 0 ? r + D : (r >= D ? r - D : r);
-                mm[w] = mv[rw[w]];
+                rw[w] = d0 - 2 + w;
+                mm[w] = mvx[d0 + w];
             }
+            if (i == 0) {
+                const int fix = (g4 == 0) ? D : 0;
+                rw[0] += fix;
+                rw[1] += fix;
+            }
+            if (i == 2) rw[6] -= (d0 == D - 4) ? D : 0;
             // per state index d = d0 + q (position q + 2 of the window): the drift at the mean
             // plus A m - b, and the two mean factors of the quadratic term
             double kq[4], aq[4], bq[4], si[4];
@@ -539,17 +552,16 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
                 double o[7];
 #pragma unroll
                 for (int w = 0; w < 7; ++w) {
-                    const double x = buf[rw[w] * LD + col];
-                    o[w] = (rw[w] >= col) ? cs * x : 0.0;
+                    o[w] = *((rw[w] >= col) ? buf + rw[w] * LD + col : zslot);      // L' is lower triangular
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // With x+- = m +- o the residuals of the two sigma points are
                     //   r+- = (a +- de)(b +- ep) - (m0 +- o0) + theta + base +- c G
-                    // so  (r+ + r-)/2 = k + de ep   and   (r+ - r-)/2 = a ep + de b - o0 + c G.
+                    // so  (r+ + r-)/2 = k + de ep   and   (r+ - r-)/2 = a ep + de b - o0 + G'  (G' = A L' = c G).
                     const double de = o[q + 3] - o[q], ep = o[q + 1];
                     const double sp = fma(de, ep, kq[q]);
-                    const double dp = fma(aq[q], ep, fma(de, bq[q], fma(cs, G[j][q], -o[q + 2])));
+                    const double dp = fma(aq[q], ep, fma(de, bq[q], G[j][q] - o[q + 2]));
                     const double t = fma(dp, dp, sp * sp);             // (r+^2 + r-^2) / 2
                     hp[j] = fma(si[q], t, hp[j]);
                     hq[j] = fma(si[q] * sp, dp, hq[j]);                // (r+^2 - r-^2) / 4
@@ -578,7 +590,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
             for (int j = 0; j < 3; ++j) {
                 const int col = 16 * j + c16;
                 if (col < D) {
-                    const double gk = 0.25 * hp[j] - 0.5 * Esde;       // (v+ + v-)/8 - Esde/2
+                    const double gk = c2 * (0.25 * hp[j] - 0.5 * Esde);   // c2 ((v+ + v-)/8 - Esde/2): W = sqrt(c2) W'
                     const double sq = sqrt(fabs(gk));
                     uv[col] = 4.0 * hq[j];                            // v+ - v-
                     sav[col] = sq;
@@ -622,8 +634,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = 4 * s + g4;
-                const double v = buf[(16 * J + c16) * LD + 16 * J + k + 2];
-                o[s] = (c16 <= k) ? v : 0.0;
+                o[s] = *((c16 <= k) ? buf + (16 * J + c16) * LD + 16 * J + k + 2 : zslot);
             }
         };
         // A operand -T_I: element [rho][k] = -T_I[pi][k] (NV valid rows / columns)
@@ -631,8 +642,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = 4 * s + g4;
-                const double v = buf[min(16 * I + k, D - 1) * LD + 16 * I + pi + 2];
-                o[s] = (k <= pi && pi < NV) ? -v : 0.0;
+                o[s] = -*((k <= pi && pi < NV) ? buf + (16 * I + k) * LD + 16 * I + pi + 2 : zslot);
             }
         };
         auto xs_wr = [&](const wv_f64x4& t) {
@@ -767,7 +777,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
                 for (int q = 0; q < 4; ++q) basev[16 * i + 4 * g4 + q] = ym[i][q];
         }
         wave_lds_fence();
-        if (lane < D) a.dEdm[e * D + lane] = 0.5 * w1 * cs * basev[lane];
+        if (lane < D) a.dEdm[e * D + lane] = 0.5 * w1 * c2 * basev[lane];      // (w c / 2) W' u, W = sqrt(c2) W'
     WV_STAMP(25);
         double* Gd = a.dEdS + e * DD;
 #pragma unroll
