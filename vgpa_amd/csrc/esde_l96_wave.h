@@ -47,6 +47,8 @@ typedef double wv_f64x4 __attribute__((ext_vector_type(4)));
 
 #ifdef VGPA_STAMPS
 #define WV_STAMP(k) do { if (blockIdx.x == 1000 && blockIdx.y == 30 && threadIdx.x == 0) g_l96_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(VGPA_PHASE_MARKS)
+#define WV_STAMP(k) asm volatile("; WVPHASE " #k)      /* a comment in the ISA listing, for instruction counts per phase */
 #else
 #define WV_STAMP(k) do { } while (0)
 #endif
