@@ -2,15 +2,16 @@
 // eight steps in flight per CU, the matrix products on the FP64 matrix cores.
 //
 // Everything a step needs sits in one 40 x 42 LDS matrix `buf` (plus a 16 x 16 scratch
-// tile and a few vectors, 18.7 KB in all) and in registers; there is no block barrier.
+// tile, a few vectors and a dump area, 20 KB in all) and in registers; no block barrier.
 //
-//   buf, lower triangle:  S(t) -> L = chol(S) -> W = L^-1, block by block in place
-//   buf, upper triangle:  the inverses T_J of the 16 x 16 diagonal blocks of L, stored
-//                         transposed and shifted one column to the right:
-//                         T_J[a][b] (b <= a) is buf[16 J + b][16 J + a + 1]
+//   buf, lower triangle:  c2 S(t) -> L' = chol(c2 S) -> W' = L'^-1, block by block in place
+//                         (c2 = D + kappa: L' = sqrt(c2) L holds the sigma-point offsets)
+//   buf, upper triangle:  the inverses T_J of the 16 x 16 diagonal blocks of L', stored
+//                         transposed and shifted two columns to the right:
+//                         T_J[a][b] (b <= a) is buf[16 J + b][16 J + a + 2]
 //   registers:            A(t) as matrix-core operand fragments (loaded straight from
-//                         global memory, in flight during the factorisation), the tiles of
-//                         G = A L, the tiles of dEsde/dS
+//                         global memory, in flight during the factorisation), one tile row
+//                         of G' = A L' at a time, the tiles of dEsde/dS
 //
 // Matrix-core tiles are 16 x 16 on the 40 x 40 matrices padded to 48 x 48 (instruction
 // v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
@@ -19,29 +20,32 @@
 // result registers of a lane are four CONSECUTIVE matrix rows 4 (l >> 4) + reg; the
 // Lorenz-96 drift couples rows d-2 .. d+1, which a lane then reads once for all four.
 // Rows / columns 40..47 do not exist: operand rows are clamped (finite duplicates) or
-// masked to zero and the results are never stored.
+// read as zero and the results are never stored.
 //
 // Phases, all wave-synchronous:
-//   1  issue the loads: m, b, Sigma^-1, S(t) (16-byte coalesced, to LDS), A(t) fragments
-//   2  blocked Cholesky, block width 16.  Diagonal block: every lane owns 4 entries of a
-//      row (row r = l >> 2); per pivot the pivot row of the block and of the accumulated
-//      row operations M is broadcast through LDS and every lane eliminates its row,
-//      which yields U = D L~' and M = L~^-1 together (S = L~ D L~'), hence L = U' D^-1/2
-//      and T = D^-1/2 M.  Panel below: L_IJ = S_IJ T_J' and trailing update
-//      S_IK -= L_IJ L_KJ' on the matrix cores.
+//   1  issue the loads: m, b, Sigma^-1, S(t) (16-byte pieces, three rows per instruction,
+//      to LDS times c2), A(t) fragments
+//   2  blocked Cholesky, block width 16.  Diagonal block in registers: lane c of the first
+//      row of 16 lanes holds column c of the block, lane c of the second row column c of
+//      the accumulated row operations M; per pivot every lane eliminates its column with
+//      multipliers broadcast by DPP (see wv_factor_diag), which yields U = D L~' and
+//      M = L~^-1 together (S = L~ D L~'), hence L = U' D^-1/2 and T = D^-1/2 M.  Panel
+//      below: L_IJ = S_IJ T_J' and trailing update S_IK -= L_IJ L_KJ' on the matrix cores.
 //   3  <f>, A m - b, optionally <df/dx>
-//   4  G = A L on the matrix cores, then the +/- sigma-point residuals of every entry,
-//      reduced over the state index within the lane and across the four lane groups
+//   4  per tile row: G' = A L' on the matrix cores, then the +/- sigma-point residuals of
+//      every entry in sum / difference form, reduced over the state index within the lane
+//      and across the four lane groups
 //   5  Esde(t), u = v+ - v-, g
-//   6  W = L^-1 in place: W_IJ = -T_I sum_K L_IK W_KJ (matrix cores, one scratch tile)
-//   7  dEsde/dm = (w c / 2) W' u (vector), dEsde/dS = W' diag(g) W (matrix cores).  Both
-//      operands are scaled by sqrt|g_k| (one with the sign of g_k), so that entry (i, j)
-//      and entry (j, i) are sums of identical products in identical order: the result is
-//      bitwise symmetric, as the symmetric backward scan requires.
+//   6  W' = L'^-1 in place: W_IJ = -T_I sum_K L_IK W_KJ (matrix cores, one scratch tile);
+//      the part above the diagonal is zeroed
+//   7  one pass over the rows of W': dEsde/dS = W' diag(g) W and W'u on the matrix cores.
+//      Both operands of the first are scaled by sqrt|g_k| (one with the sign of g_k), so
+//      that entry (i, j) and entry (j, i) are sums of identical products in identical
+//      order: the result is bitwise symmetric, as the symmetric backward scan requires.
 //
 // A step whose S(t) is not positive definite is flagged for the fallback pass exactly as
-// by the tiled kernel.  Included by esde.hip inside its anonymous namespace, after
-// esde_l96_tiled.h (shares rcp_refined, rsqrt_refined, wave_lds_fence, wave_sum).
+// by the workgroup-per-step kernel.  Included by esde.hip inside its anonymous namespace,
+// after esde_l96_tiled.h (shares rcp_refined, rsqrt_refined, wave_lds_fence, readlane_f64).
 
 typedef double wv_f64x4 __attribute__((ext_vector_type(4)));
 
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double* dump = lds + C::OFF_DUMP;
     const double* zslot = lds + C::OFF_ZERO;       // holds 0.0: masked loads select this address
     const int lane0 = threadIdx.x;
-    constexpr int NQ = (DD / 2 + 63) / 64;         // 13 sixteen-byte pieces of S(t) per lane
+    constexpr int NQ3 = (D + 2) / 3;               // 14 load instructions of three rows of S(t) each
     const int p = blockIdx.y;                      // problem, step: no division by N
     const size_t e = (size_t)p * a.N + blockIdx.x;
     // The lane index is made opaque again at every phase: addresses and masks derived from it
@@ -253,27 +257,26 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     // ---- phase 1: loads; c2 S(t) goes to LDS -------------------------------------------------
     // Everything below works with L' = chol(c2 S) = sqrt(c2) L, the sigma-point offsets
     // themselves, and W' = L'^-1 = W / sqrt(c2); the factors c2 are put back at the outputs.
-    double sx[NQ], sy[NQ];
+    // Sixteen-byte pieces: instruction i moves rows 3 i .. 3 i + 2, lane l (< 60) the piece
+    // (row 3 i + l / 20, column pair l % 20); every address is one per-lane base plus a
+    // compile-time offset.  Lanes 60..63 repeat lane 59.
     {
-        const double2* Sg = reinterpret_cast<const double2*>(a.S + e * DD);
+        const int l60 = min(lane, 59);
+        const int lr = (l60 >= 20) + (l60 >= 40), lc = l60 - 20 * lr;
+        const double2* src = reinterpret_cast<const double2*>(a.S + e * DD) + lr * (D / 2) + lc;
+        double sx[NQ3], sy[NQ3];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const double2 v = Sg[min(i * 64 + lane, DD / 2 - 1)];
+        for (int i = 0; i < NQ3; ++i) {
+            // the last instruction has row 39 only: the other lanes repeat its pieces
+            const double2 v = (i < NQ3 - 1) ? src[i * 3 * (D / 2)] : src[i * 3 * (D / 2) - lr * (D / 2)];
             sx[i] = v.x;
             sy[i] = v.y;
         }
-    }
-    {
-        // piece q = 64 i + lane is row q / 20, column pair q % 20; 64 = 3 * 20 + 4
-        int row = (lane >= 20) + (lane >= 40) + (lane >= 60), cp = lane - 20 * row;
+        double* dst = buf + lr * LD + 2 * lc;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            double* dst = (i < NQ - 1 || lane < DD / 2 - 64 * (NQ - 1)) ? buf + row * LD + 2 * cp : dump + 2 * lane;
-            *reinterpret_cast<double2*>(dst) = make_double2(c2 * sx[i], c2 * sy[i]);
-            cp += 4;
-            row += 3 + (cp >= 20 ? 1 : 0);
-            cp -= (cp >= 20 ? 20 : 0);
-        }
+        for (int i = 0; i < NQ3 - 1; ++i)
+            *reinterpret_cast<double2*>(dst + i * 3 * LD) = make_double2(c2 * sx[i], c2 * sy[i]);
+        *reinterpret_cast<double2*>(dst + (NQ3 - 1) * 3 * LD - lr * LD) = make_double2(c2 * sx[NQ3 - 1], c2 * sy[NQ3 - 1]);
     }
     const int lv = min(lane, D - 1);
     const double m_l = a.m[e * D + lv];
