@@ -67,7 +67,7 @@ struct L96Wave {
     // address select instead of an exec-mask region); a slot takes the four rows of a tile.
     static constexpr int OFF_DUMP = OFF_VEC + 7 * VL;
     static constexpr int OFF_ZERO = OFF_DUMP + 64 + 3 * LD;        // dump >= 128: two doubles per lane as well
-    static constexpr int LDS_DOUBLES = OFF_ZERO + 2;               // one 0.0: what a masked operand load reads
+    static constexpr int LDS_DOUBLES = OFF_ZERO + 16;              // zeros: what a masked operand load reads
 };
 
 __device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
@@ -137,15 +137,14 @@ struct WvElim {
 };
 template <int K, int NP>
 struct WvPivots {
-    static __device__ __forceinline__ void run(double (&x)[NP], int c, double& pmin, double& pivc) {
+    static __device__ __forceinline__ void run(double (&x)[NP], int c, double& pivc) {
         if constexpr (K < NP) {
             const double piv = wv_row_bcast<K>(x[K]);           // S rows: S[k][k]; M rows: 1
-            pmin = fmin(pmin, piv);
             pivc = (c == K) ? piv : pivc;
             // multipliers -S[k][i] / S[k][k] in lane i of the S rows, copied to the M rows
             const double ntk = wv_even_rows_to_odd(x[K] * -rcp_refined(piv));
             WvElim<K, K + 1, NP>::run(x, ntk);
-            WvPivots<K + 1, NP>::run(x, c, pmin, pivc);
+            WvPivots<K + 1, NP>::run(x, c, pivc);
         }
     }
 };
@@ -171,41 +170,49 @@ struct WvScale {
 // the pivot chain.  Returns false on a pivot <= 0 (a NaN pivot is not flagged: it poisons the
 // outputs of the step instead).
 template <int J>
-__device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, int lane) {
+__device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, const double* zeros, int lane) {
     constexpr int LD = L96Wave::LD, c0 = 16 * J, NP = (J == 2) ? 8 : 16;
     const int c = lane & 15;
     const bool is_m = (lane & 16) != 0;
     double x[NP];
     {
-        const double* src = buf + (c0 + min(c, NP - 1)) * LD + c0;     // column c = row c (symmetric)
+        // S lanes: column c = row c (symmetric); M lanes: sixteen zeros, then the one of I
+        const double* src = is_m ? zeros : buf + (c0 + min(c, NP - 1)) * LD + c0;
 #pragma unroll
         for (int h = 0; h < NP / 2; ++h) {
             const double2 v = *reinterpret_cast<const double2*>(src + 2 * h);
             x[2 * h] = v.x;
             x[2 * h + 1] = v.y;
         }
+        const int cm = is_m ? c : -1;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) x[i] = is_m ? ((i == c) ? 1.0 : 0.0) : x[i];
+        for (int i = 0; i < NP; ++i) x[i] = __hiloint2double((i == cm) ? 0x3ff00000 : __double2hiint(x[i]), __double2loint(x[i]));
     }
-    double pmin = 1.0;             // smallest pivot so far (a running minimum keeps no pivot alive)
-    double pivc = 1.0;             // pivot of row c (S rows)
-    WvPivots<0, NP>::run(x, c, pmin, pivc);
+    double pivc = 1.0;             // pivot of row c (S rows; 1 in the M rows and the padding)
+    WvPivots<0, NP>::run(x, c, pivc);
     const double rsc = wv_even_rows_to_odd(rsqrt_refined(pivc));
     WvScale<0, NP>::run(x, rsc);
     // S lane c: L[c][k] = x[k] for k <= c, to buf[c0 + c][c0 + k]
     // M lane c: T[i][c] = x[i] for i >= c, to buf[c0 + c][c0 + i + 2]
+    // In 16-byte pieces h = 0 .. NP/2 - 1: an S lane writes the pieces h <= c / 2, an M lane the
+    // pieces h >= c / 2 (the half-used piece spills into the free superdiagonal); every other
+    // piece, and every lane beyond the block, goes to the lane's dump slot.
     {
+        const int hc = c >> 1;
         const bool lane_writes = lane < 32 && c < NP;
+        const unsigned first = is_m ? hc : 0;                            // pieces first .. first + count - 1
+        const unsigned count = lane_writes ? (is_m ? NP / 2 - hc : hc + 1) : 0;
         double* dst = buf + (c0 + c) * LD + c0 + (is_m ? 2 : 0);
         double* nowhere = dump + 2 * lane;
 #pragma unroll
         for (int h = 0; h < NP / 2; ++h) {
-            const bool wr = lane_writes && (is_m ? (2 * h + 1 >= c) : (2 * h <= c));
+            const bool wr = (unsigned)h - first < count;
             *reinterpret_cast<double2*>(wr ? dst + 2 * h : nowhere) = make_double2(x[2 * h], x[2 * h + 1]);
         }
     }
     wave_lds_fence();
-    return __builtin_amdgcn_ballot_w64(!(pmin > 0.0)) == 0;
+    // every pivot is the pivc of one S lane
+    return __builtin_amdgcn_ballot_w64(!(pivc > 0.0)) == 0;
 }
 
 // indices l + 1, l - 1, l - 2 on the ring of D = 40 components
@@ -298,7 +305,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         sIv[lane] = lane < D ? si_l : 0.0;
         basev[lane] = 0.0;
     }
-    if (lane < 2) lds[C::OFF_ZERO + lane] = 0.0;
+    if (lane < 16) lds[C::OFF_ZERO + lane] = 0.0;
     wave_lds_fence();
 
     // the covariance term of <f>, before S is overwritten by its factor
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q * LD] = 0.0;
     };
-    bool ok = wv_factor_diag<0>(buf, dump, lane);
+    bool ok = wv_factor_diag<0>(buf, dump, zslot, lane);
     WV_STAMP(27);
     {
         // block column 0: panel L_10, L_20 = S_I0 T_0'
@@ -388,7 +395,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     }
     WV_STAMP(28);
     WV_RELANE();
-    ok = wv_factor_diag<1>(buf, dump, lane) && ok;
+    ok = wv_factor_diag<1>(buf, dump, zslot, lane) && ok;
     WV_STAMP(29);
     {
         // block column 1: panel L_21 = S_21 T_1'
@@ -423,7 +430,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     }
     WV_STAMP(30);
     WV_RELANE();
-    ok = wv_factor_diag<2>(buf, dump, lane) && ok;
+    ok = wv_factor_diag<2>(buf, dump, zslot, lane) && ok;
 
     WV_STAMP(18);
     WV_RELANE();
