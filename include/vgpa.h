@@ -287,6 +287,34 @@ int vgpa_scg_update(int P, long long nA, long long nb, double* x, const double* 
                     const double* g_try, double* d, const double* gamma, const int* mode, int nch,
                     double* work, double* out, void* stream);
 
+/*
+ * Sample paths of the stochastic systems, P independent paths at once: replaces the
+ * recursions of `system_path` in dynamics/sys_ornstein_uhlenbeck.py:15-61,
+ * dynamics/sys_double_well.py:14-75, dynamics/sys_lorenz_63.py:42-106 (and _ut.py:49-113),
+ * dynamics/sys_lorenz_96_ut.py:43-111.  From x0 (P,D): `burn` deterministic Euler steps of
+ * size dtau (the burn-in loops :83-84 / :38-40; 0 for none), then X[0] = x + add0 (add0 (P,D)
+ * or NULL) and X[t] = X[t-1] + f(X[t-1]) dt + kdiag .* noise[t] for t = 1..N-1.  The caller
+ * supplies the random numbers noise (P,N,D) (row 0 is not used, as in the reference) and
+ * kdiag = sqrt(diag(sig0) dt) as (D) (k_stride 0) or (P,D) (k_stride D); theta as for
+ * vgpa_esde.  Sums and products round separately in the order of the reference's NumPy
+ * expressions: with the same random numbers the path has the same bits.   -> X (P,N,D).
+ */
+int vgpa_sde_path(int system, int P, int N, int D, const double* x0, const double* add0,
+                  const double* theta, int theta_stride, const double* kdiag, int k_stride,
+                  int burn, double dtau, double dt, const double* noise, double* X, void* stream);
+
+/*
+ * Starting values of the variational parameters from interpolated means: replaces the
+ * n-dimensional branch of auxiliary/initialize_Ab0.py:66-93.  mt0 (P,N,D) are the spline
+ * means (the splines themselves, :74-77, stay on the host: SciPy FITPACK), sig_diag and
+ * s0_diag the diagonals of Sigma and S0 as (D) (stride 0) or (P,D) (stride D).
+ *   -> A0 (P,N,D,D) = 0.5 diag(Sigma_ii / S0_ii),
+ *      b0 (P,N,D)   = (mt0[k+1] - mt0[k]) / dt + A_ii mt0[k],  last row A_ii mt0[N-1].
+ */
+int vgpa_init_ab0(int P, int N, int D, const double* mt0, const double* sig_diag, int sig_stride,
+                  const double* s0_diag, int s0_stride, double dt, double* A0, double* b0,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

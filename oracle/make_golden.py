@@ -359,18 +359,76 @@ def golden_scg(ref, outdir):
     print("wrote scg_l63: fx", fx, "f_eval", stat["f_eval"], "MaxIt", stat["MaxIt"])
 
 
+def golden_prep(ref, outdir):
+    """Input preparation: seeded sample paths of every system, observations collected from
+    them, and the starting values A0, b0.  The fixture holds the seed and the arguments;
+    the consumer re-seeds ``numpy.random`` and must obtain the same arrays."""
+    import contextlib
+    import io
+    from auxiliary import collect_obs as ref_collect, initialize_Ab0 as ref_init
+    rec = {}
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    T = np.arange(0.0, 0.6, 0.01)
+    with quiet:
+        np.random.seed(101)
+        rec["ou_T"], rec["ou_sig"], rec["ou_theta"] = T, np.float64(0.8), np.float64(2.0)
+        rec["ou_X"] = ref["ou"].system_path(T, 0.8, 2.0)
+        np.random.seed(102)
+        rec["dw_T"], rec["dw_sig"], rec["dw_theta"] = T, np.float64(0.8), np.float64(1.0)
+        rec["dw_X"] = ref["dw"].system_path(T, 0.8, 1.0)
+        th63 = np.array([10.0, 28.0, 8.0 / 3.0])
+        sig63 = np.diag([6.0, 7.0, 8.0])
+        np.random.seed(103)
+        rec["l63_T"], rec["l63_sig"], rec["l63_theta"] = T, sig63, th63
+        rec["l63_X"] = ref["l63"].system_path(T, sig63, th63)
+        np.random.seed(104)
+        rec["l63_ut_X"] = ref["l63_ut"].system_path(T, sig63, th63)
+        D = 40
+        sig96 = 4.0 * np.eye(D)
+        np.random.seed(105)
+        rec["l96_T"], rec["l96_sig"], rec["l96_theta"] = T, sig96, np.float64(8.0)
+        rec["l96_X"] = ref["l96_ut"].system_path(T, D, sig96, 8.0)
+        np.random.seed(106)
+        rec["l96s_X"] = ref["l96_ut"].system_path(T, 6, 2.5, 8.0)         # scalar noise variance, D = 6
+    # observations: scalar R (one random number per time), vector R with a mask
+    Tl = np.arange(0.0, 2.0, 0.01)
+    with quiet:
+        np.random.seed(107)
+        path = ref["l63_ut"].system_path(Tl, sig63, th63)
+    rec["obs_T"], rec["obs_path"] = Tl, path
+    np.random.seed(108)
+    oX, oY = ref_collect.collect_obs(path, Tl, 4, 2.0)
+    rec["obs1_X"], rec["obs1_Y"] = np.asarray(oX, dtype=np.int64), oY
+    np.random.seed(109)
+    oX2, oY2 = ref_collect.collect_obs(path, Tl, 2, np.array([1.0, 2.0]), [0, 2])
+    rec["obs2_X"], rec["obs2_Y"] = np.asarray(oX2, dtype=np.int64), oY2
+    # starting values, D = 3 and D = 1
+    S0 = np.diag([0.25, 0.5, 0.75])
+    sde = dict(Sig=sig63, N=len(Tl), D=3, Tw=Tl, obsX=oX, obsY=oY, dt=0.01)
+    rec["ab0_S0"], rec["ab0_vec"] = S0, ref_init.initialize_Ab0(S0, sde)
+    sde1 = dict(Sig=0.8, N=len(Tl), D=1, Tw=Tl, obsX=oX, obsY=oY[:, :1], dt=0.01)
+    rec["ab0_1d_S0"], rec["ab0_1d_vec"] = np.float64(0.3), ref_init.initialize_Ab0(0.3, sde1)
+    np.savez_compressed(os.path.join(outdir, "prep.npz"), **rec)
+    print("wrote prep:", {k: v.shape for k, v in rec.items() if hasattr(v, "shape") and v.ndim})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="'prep': only the input-preparation fixture")
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: fixtures can only be regenerated in the build container")
     os.makedirs(args.out, exist_ok=True)
     ref = _import_reference()
+    if args.only == "prep":
+        golden_prep(ref, args.out)
+        return
     golden_systems(ref, args.out)
     golden_units(ref, args.out)
     golden_nonpd_energy(ref, args.out)
     golden_scg(ref, args.out)
+    golden_prep(ref, args.out)
 
 
 if __name__ == "__main__":

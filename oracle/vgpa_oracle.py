@@ -652,3 +652,47 @@ def evaluate(system, Ab, m0, S0, sde, with_grad=True, outer=False):
     if with_grad:
         out["grad"] = grad_L_Ab(A, b, m, S, lam, Psi, Ef, Edf, sde["Sig"], dt, outer=outer)
     return out
+
+
+# ---------------------------------------------------------------------------
+# input preparation: sample paths and starting values (test infrastructure)
+# ---------------------------------------------------------------------------
+def path_drift(system, x, theta):
+    """Drift of the stochastic systems at state x (D,): dynamics/sys_ornstein_uhlenbeck.py:58,
+    sys_double_well.py:72, sys_lorenz_63.py:32-34, sys_lorenz_96_ut.py:36-38, in the
+    reference's order of operations."""
+    if system == "ou":
+        return theta * (0 - x)
+    if system == "dw":
+        return 4 * x * (theta - x ** 2)
+    if system in ("l63", "l63_ut"):
+        s, r, b = theta
+        return np.array([-s * (x[0] - x[1]), (r - x[2]) * x[0] - x[1], x[0] * x[1] - b * x[2]])
+    return (np.roll(x, -1) - np.roll(x, +2)) * np.roll(x, +1) - x + theta
+
+
+def sde_path(system, x0, theta, kdiag, ek, dt, burn=0, dtau=0.0, add0=None):
+    """The recursion of ``system_path`` (sys_lorenz_96_ut.py:82-106 and its siblings):
+    ``burn`` deterministic Euler steps of size dtau from x0, X[0] = x (+ add0), then
+    X[t] = X[t-1] + f(X[t-1]) dt + kdiag * ek[t]."""
+    x = np.array(x0, dtype=np.float64).reshape(-1)
+    for _ in range(burn):
+        x = x + path_drift(system, x, theta) * dtau
+    N, D = ek.shape
+    X = np.zeros((N, D))
+    X[0] = x if add0 is None else x + add0
+    for t in range(1, N):
+        X[t] = X[t - 1] + path_drift(system, X[t - 1], theta) * dt + ek[t] * kdiag
+    return X
+
+
+def init_ab0(mt0, sig_diag, s0_diag, dt):
+    """auxiliary/initialize_Ab0.py:80-93 for given spline means mt0 (N,D): A0 (N,D,D), b0 (N,D)."""
+    N, D = mt0.shape
+    aii = 0.5 * (sig_diag / s0_diag)
+    A0 = np.zeros((N, D, D))
+    A0[:, np.arange(D), np.arange(D)] = aii
+    b0 = np.zeros((N, D))
+    b0[:-1] = np.diff(mt0, axis=0) / dt + aii * mt0[:-1]
+    b0[-1] = aii * mt0[-1]
+    return A0, b0

@@ -21,7 +21,7 @@ def test_aliases_resolve_to_this_package():
     saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("core", "dynamics", "auxiliary")}
     try:
         names = compat.install()
-        assert len(names) == 15
+        assert len(names) == 17
         import core.fwd_ode
         import dynamics.sys_double_well as dw
         from auxiliary.momGauss import momGauss

@@ -54,6 +54,9 @@ SIGNATURES = {
     "vgpa_ut_moments": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "vgpa_grad_esde_ms": [_c_int, _c_int] + [_ptr] * 8 + [_ptr],
     "vgpa_mom_gauss": [ctypes.c_longlong, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
+    "vgpa_sde_path": [_c_int] * 4 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, ctypes.c_double, ctypes.c_double,
+                      _ptr, _ptr, _ptr],
+    "vgpa_init_ab0": [_c_int] * 3 + [_ptr, _ptr, _c_int, _ptr, _c_int, ctypes.c_double, _ptr, _ptr, _ptr],
     "vgpa_scg_dots": [_c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr],
     "vgpa_scg_step": [_c_int, ctypes.c_longlong, ctypes.c_longlong] + [_ptr] * 6 + [_ptr],
     "vgpa_scg_curvature": [_c_int, ctypes.c_longlong, ctypes.c_longlong] + [_ptr] * 4 + [_c_int, _ptr, _ptr, _ptr],

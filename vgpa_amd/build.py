@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SRC = [os.path.join(CSRC, f) for f in ("common.hip", "scan.hip", "esde.hip", "assemble.hip", "ut.hip", "scg.hip")]
+SRC = [os.path.join(CSRC, f) for f in ("common.hip", "scan.hip", "esde.hip", "assemble.hip", "ut.hip", "scg.hip", "path.hip")]
 OUT = os.path.join(HERE, "lib", "libvgpa_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include")]

@@ -4,10 +4,10 @@
 reference imports (``core.varFreeEnergy``, ``core.gradL_Ab``, ``core.fwd_ode``,
 ``core.bwd_ode``, ``core.likelihood``, ``core.kl0``, ``core.gradEsde_mS``,
 ``dynamics.sys_*``, ``auxiliary.numerical``, ``auxiliary.momGauss``,
-``auxiliary.optimize``).  Modules the reference has and this package does not
-replace (``core.smoothing``, ``auxiliary.collect_obs``, ``auxiliary.initialize_Ab0``)
-keep coming from the reference tree when it is on ``sys.path``; its
-``core/smoothing.py:5-10`` then binds to the functions registered here.
+``auxiliary.optimize``, ``auxiliary.collect_obs``, ``auxiliary.initialize_Ab0``).  The
+module the reference has and this package does not replace (``core.smoothing``) keeps
+coming from the reference tree when it is on ``sys.path``; its ``core/smoothing.py:5-10``
+then binds to the functions registered here.
 """
 import importlib
 import sys
@@ -29,6 +29,8 @@ _ALIASES = {
     "auxiliary.numerical": "vgpa_amd.auxiliary.numerical",
     "auxiliary.momGauss": "vgpa_amd.auxiliary.momGauss",
     "auxiliary.optimize": "vgpa_amd.auxiliary.optimize",
+    "auxiliary.collect_obs": "vgpa_amd.auxiliary.collect_obs",
+    "auxiliary.initialize_Ab0": "vgpa_amd.auxiliary.initialize_Ab0",
 }
 
 

@@ -1,12 +1,29 @@
 """Expected SDE energy for the Lorenz-63 with analytic Gaussian moments.
 
-Counterpart of ``energy_mode`` in dynamics/sys_lorenz_63.py:125; trajectory generation and plotting
-of that file are outside this package.
+Counterpart of ``energy_mode`` in dynamics/sys_lorenz_63.py:125 and of ``system_path`` (dynamics/sys_lorenz_63.py:42);
+plotting is outside this package.
 """
+import numpy as np
+
 from .. import _lib
+from . import _path
 from ._energy import energy_mode as _energy_mode
 
-__all__ = ["energy_mode"]
+__all__ = ["system_path", "energy_mode"]
+
+
+def system_path(T, sig0, thet0):
+    """A realisation of the stochastic Lorenz-63 system on the time window T -> (N, 3)
+    (dynamics/sys_lorenz_63.py:42-106): 8000 deterministic burn-in steps of 1e-3 from
+    (1, 1, 1), a standard-normal perturbation of the starting point, then Euler-Maruyama
+    with ``np.random.randn(N, 3)``."""
+    print('Lorenz 1963 - trajectory')
+    dt = np.diff(T)[0]
+    N = len(T)
+    add0 = np.random.standard_normal(3)
+    kdiag = _path.noise_scale(sig0, dt, 3)
+    ek = np.random.randn(N, 3)
+    return _path.run(_lib.SYS_L63, np.ones(3), thet0, kdiag, ek, dt, burn=8000, dtau=1.0e-3, add0=add0)
 
 
 def energy_mode(A, b, m, S, sDyn):

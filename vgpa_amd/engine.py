@@ -381,6 +381,26 @@ def mom_gauss(m, S, order, deriv):
     return out
 
 
+def sde_paths(system, x0, theta, kdiag, noise, dt, burn=0, dtau=0.0, add0=None):
+    """vgpa_sde_path: x0 (P,D), theta (n,) / (P,n), kdiag (D,) / (P,D), noise (P,N,D) -> X (P,N,D)."""
+    P, N, D = noise.shape
+    n_theta = 3 if system in (_lib.SYS_L63, _lib.SYS_L63_UT) else 1
+    X = torch.empty((P, N, D), dtype=F64, device=noise.device)
+    call("vgpa_sde_path", system, P, N, D, _p(x0), _p(add0), _p(theta), _par_stride(theta, P, n_theta),
+         _p(kdiag), _par_stride(kdiag, P, D), int(burn), float(dtau), float(dt), _p(noise), _p(X), _stream())
+    return X
+
+
+def init_ab0(mt0, sig_diag, s0_diag, dt):
+    """vgpa_init_ab0: mt0 (P,N,D), diagonals (D,) / (P,D) -> A0 (P,N,D,D), b0 (P,N,D)."""
+    P, N, D = mt0.shape
+    A0 = torch.empty((P, N, D, D), dtype=F64, device=mt0.device)
+    b0 = torch.empty((P, N, D), dtype=F64, device=mt0.device)
+    call("vgpa_init_ab0", P, N, D, _p(mt0), _p(sig_diag), _par_stride(sig_diag, P, D), _p(s0_diag),
+         _par_stride(s0_diag, P, D), float(dt), _p(A0), _p(b0), _stream())
+    return A0, b0
+
+
 # ---------------------------------------------------------------------------
 # the evaluation
 # ---------------------------------------------------------------------------
