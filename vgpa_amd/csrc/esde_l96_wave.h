@@ -511,6 +511,18 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
     double mb[3][4] = {};
     {
+        // the B operands L'[4 s + g4][16 j + c16], s >= 4 j (L' is lower triangular: in the
+        // diagonal blocks the entries above the diagonal are read as zero)
+        double lb[3][10];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = 16 * j + c16;
+#pragma unroll
+            for (int s = 4 * j; s < 10; ++s) {
+                const int k = 4 * s + g4;
+                lb[j][s] = *((s < 4 * j + 4 && k < col) ? zslot : buf + k * LD + col);
+            }
+        }
         // one tile row of G at a time (the three tiles of a row share the A fragments, and
         // only 24 result registers are alive at once)
 #pragma unroll
@@ -519,14 +531,8 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 G[j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
-                const int col = 16 * j + c16;
 #pragma unroll
-                for (int s = 4 * j; s < 10; ++s) {
-                    const int k = 4 * s + g4;
-                    // diagonal block: only the lower triangle is L'
-                    const double* src = (s < 4 * j + 4 && k < col) ? zslot : buf + k * LD + col;
-                    G[j] = wv_mfma(af[i][s], *src, G[j]);
-                }
+                for (int s = 4 * j; s < 10; ++s) G[j] = wv_mfma(af[i][s], lb[j][s], G[j]);
             }
             const int d0r = 16 * i + 4 * g4;
             const bool rows_valid = d0r < D;
