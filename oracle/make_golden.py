@@ -412,23 +412,111 @@ def golden_prep(ref, outdir):
     print("wrote prep:", {k: v.shape for k, v in rec.items() if hasattr(v, "shape") and v.ndim})
 
 
+def golden_callers(ref, outdir):
+    """Two callers of the path, recorded from the reference:
+
+    * three updates of the drift-parameter estimation loop of
+      lorenz-63-parameter-estimation.py:189-277 (smoothing with the reference's
+      ``smoothing.smoothing``, dEsde/dtheta from ``energy_mode`` at the optimum, theta
+      <- theta - rate * gradient), on the N = 41 unscented Lorenz-63 fixture.  The
+      script's ``run_smoothing`` draws a random m0 and builds spline starting values;
+      here both are the fixture's fixed arrays so that the run can be repeated.
+    * ``finiteDiff(varFreeEnergy, x, mParam)`` (auxiliary/numerical.py:89-150) on the
+      N = 41 analytic Lorenz-63 fixture: 2 n evaluations of the free energy.
+    """
+    import contextlib
+    import io
+    from core import smoothing
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    Ab0, m0, S0, sde = build_nd("l63_ut", 3, 41, 14)          # the inputs of sys_l63_ut.npz
+    dyn = ref["l63_ut"]
+    theta = np.array(sde["theta"]) * np.array([0.9, 1.05, 1.1])
+    rate, nit_outer, scg_nit = 1.0e-2, 3, 8
+    thetas, costs, grads = [theta.copy()], [], []
+
+    def run_smoothing(theta_now):
+        s = deepcopy(sde)
+        s["theta"] = theta_now.copy()
+        with quiet:
+            Fmin, mParam = smoothing.smoothing(dyn.energy_mode, Ab0.copy(), m0, S0, s, scg_nit)
+        return Fmin, mParam, s
+
+    Fmin, mParam, s = run_smoothing(theta)
+    costs.append(Fmin)
+    for _ in range(nit_outer):
+        dth = dyn.energy_mode(mParam["At"], mParam["bt"], mParam["mt"], mParam["St"], s)[5]
+        grads.append(np.asarray(dth, dtype=np.float64).reshape(-1).copy())
+        theta = theta - rate * grads[-1]
+        thetas.append(theta.copy())
+        Fmin, mParam, s = run_smoothing(theta)
+        costs.append(Fmin)
+    rec = _flatten_inputs(Ab0, m0, S0, sde)
+    rec.update(rate=np.float64(rate), scg_nit=np.int64(scg_nit), thetas=np.array(thetas),
+               costs=np.array(costs, dtype=np.float64), grads=np.array(grads))
+    np.savez_compressed(os.path.join(outdir, "estimate_l63_ut.npz"), **rec)
+    print("wrote estimate_l63_ut: costs", costs, "theta", thetas[-1])
+
+    Ab, m0, S0, sde = build_nd("l63", 3, 41, 13)              # the inputs of sys_l63.npz
+    mParam = dict(m0=m0, S0=S0, fun=ref["l63"].energy_mode, sde_struct=deepcopy(sde))
+    with quiet:
+        gnum = ref["numerical"].finiteDiff(ref["varFreeEnergy"].varFreeEnergy, Ab.copy(), mParam)
+    rec = _flatten_inputs(Ab, m0, S0, sde)
+    rec.update(finite_diff=np.asarray(gnum, dtype=np.float64))
+    np.savez_compressed(os.path.join(outdir, "finite_diff_l63.npz"), **rec)
+    print("wrote finite_diff_l63:", np.asarray(gnum).shape, float(np.abs(gnum).max()))
+
+
+def golden_extras(ref, outdir):
+    """Lorenz-96 at D = 16 (the dimension of the workgroup-per-step energy kernel) and the
+    observation terms with a dense H and a non-diagonal R."""
+    Ab, m0, S0, sde = build_nd("l96_ut", 16, 9, 41, dt=0.005)
+    rec = _flatten_inputs(Ab, m0, S0, sde)
+    for method in METHODS:
+        res = run_full(ref, "l96_ut", Ab, m0, S0, sde, method, full=(method == "EULER"))
+        for k, v in res.items():
+            rec[f"{method}.{k}"] = v
+    np.savez_compressed(os.path.join(outdir, "sys_l96_ut_d16.npz"), **rec)
+    print("wrote l96_ut_d16", {m: rec[f"{m}.F"] for m in METHODS})
+
+    rng = np.random.default_rng(77)
+    D, N = 7, 30
+    X = rng.standard_normal((D, D))
+    R = 0.5 * np.eye(D) + 0.1 * X.dot(X.T)
+    H = np.eye(D) + 0.2 * rng.standard_normal((D, D))
+    obsX = np.array([2, 3, 11, 19, 28])
+    obsY = rng.standard_normal((5, D))
+    m = rng.standard_normal((N, D))
+    S = 0.3 * np.eye(D)[None] + 0.05 * rng.standard_normal((N, D, D))
+    sde = dict(D=D, N=N, dt=0.01, Rig=R, H=H, obsX=obsX, obsY=obsY)
+    Eobs, dm, dS, dR = ref["likelihood"].gauss(m, S, sde)
+    rec = dict(D=np.int64(D), N=np.int64(N), Rig=R, H=H, obsX=obsX, obsY=obsY, m=m, S=S,
+               Eobs=np.asarray(Eobs, dtype=np.float64), dEobs_dm=np.asarray(dm), dEobs_dS=np.asarray(dS),
+               dEobs_dR=np.asarray(dR, dtype=np.float64))
+    np.savez_compressed(os.path.join(outdir, "likelihood_dense.npz"), **rec)
+    print("wrote likelihood_dense: Eobs", float(np.asarray(Eobs).reshape(-1)[0]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
-    ap.add_argument("--only", default="", help="'prep': only the input-preparation fixture")
+    ap.add_argument("--only", default="", help="'prep', 'callers' or 'extras': only that group of fixtures")
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: fixtures can only be regenerated in the build container")
     os.makedirs(args.out, exist_ok=True)
     ref = _import_reference()
-    if args.only == "prep":
-        golden_prep(ref, args.out)
+    only = dict(prep=golden_prep, callers=golden_callers, extras=golden_extras)
+    if args.only:
+        only[args.only](ref, args.out)
         return
     golden_systems(ref, args.out)
     golden_units(ref, args.out)
     golden_nonpd_energy(ref, args.out)
     golden_scg(ref, args.out)
     golden_prep(ref, args.out)
+    golden_callers(ref, args.out)
+    golden_extras(ref, args.out)
 
 
 if __name__ == "__main__":

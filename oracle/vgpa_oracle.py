@@ -544,9 +544,10 @@ def energy_mode(system, A, b, m, S, sde):
         Edf = -theta * np.ones(m.shape)
         dEdm = SigInv * (m * (theta - A)**2 + theta * b - Q2)
         dEdS = 0.5 * SigInv * Q1
-        dth = SigInv * mytrapz(Ex2 * (theta - A) + m * b, dt, idx)
+        dth_t = Ex2 * (theta - A) + m * b
+        dth = SigInv * mytrapz(dth_t, dt, idx)
         dSig = -SigInv * Esde
-        return Esde, Ef, Edf, dEdm, dEdS, dth, dSig, dict(Esde_t=0.5 * SigInv * varQ)
+        return Esde, Ef, Edf, dEdm, dEdS, dth, dSig, dict(Esde_t=0.5 * SigInv * varQ, dth_t=dth_t, dSig_t=None)
     if system == "dw":                                      # sys_double_well.py:129-187
         SigInv = 1.0 / sde["Sig"]
         c = 4.0 * theta + A
@@ -560,9 +561,10 @@ def energy_mode(system, A, b, m, S, sde):
         DS = {o: mom_gauss(m, S, o, "DS") for o in (2, 3, 4, 6)}
         dEdm = 0.5 * SigInv * (16.0 * Dm[6] - 8.0 * c * Dm[4] + 8.0 * b * Dm[3] + c2 * Dm[2] - 2.0 * b * c)
         dEdS = 0.5 * SigInv * (16.0 * DS[6] - 8.0 * c * DS[4] + 8.0 * b * DS[3] + c2 * DS[2])
-        dth = 4.0 * SigInv * mytrapz(c * Ex2 - 4.0 * Ex4 - b * m, dt, idx)
+        dth_t = c * Ex2 - 4.0 * Ex4 - b * m
+        dth = 4.0 * SigInv * mytrapz(dth_t, dt, idx)
         dSig = -Esde * SigInv
-        return Esde, Ef, Edf, dEdm, dEdS, dth, dSig, dict(Esde_t=0.5 * SigInv * varQ)
+        return Esde, Ef, Edf, dEdm, dEdS, dth, dSig, dict(Esde_t=0.5 * SigInv * varQ, dth_t=dth_t, dSig_t=None)
 
     SigInv = np.linalg.inv(sde["Sig"])
     dSI = np.diag(SigInv)
@@ -652,6 +654,19 @@ def evaluate(system, Ab, m0, S0, sde, with_grad=True, outer=False):
     if with_grad:
         out["grad"] = grad_L_Ab(A, b, m, S, lam, Psi, Ef, Edf, sde["Sig"], dt, outer=outer)
     return out
+
+
+def finite_diff(fun, x, h=1.0e-6):
+    """auxiliary/numerical.py:89-150: central differences of ``fun`` (a function of the
+    column vector alone here) in every coordinate direction, step h."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1, 1)
+    grad = np.zeros_like(x)
+    e = np.zeros_like(x)
+    for i in range(x.size):
+        e[i] = 1.0
+        grad[i] = 0.5 * (fun(x + h * e) - fun(x - h * e)) / h      # :137-141
+        e[i] = 0.0
+    return grad
 
 
 # ---------------------------------------------------------------------------

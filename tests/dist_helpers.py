@@ -65,9 +65,14 @@ class OracleWindowOps:
         # time integrals (which this test does not read) well defined in empty windows
         out = orc.energy_mode(self.system, self.A, self.b, mn, Sn, dict(self.sde, obsX=np.array([self.window.rows])))
         Esde_t = np.asarray(out[7]["Esde_t"]).reshape(-1)
-        Esde = self.sde["dt"] * float(np.dot(self.w, Esde_t))
+        dt = self.sde["dt"]
+        Esde = dt * float(np.dot(self.w, Esde_t))
+        # window shares of the integrals behind dEsde/dtheta and dEsde/dSigma
+        tr_th = dt * self.w.dot(np.asarray(out[7]["dth_t"]).reshape(self.window.rows, -1))
+        tr_sig = (dt * self.w.dot(np.asarray(out[7]["dSig_t"]).reshape(self.window.rows, -1))
+                  if out[7]["dSig_t"] is not None else np.zeros(0))
         return dict(Eobs=float(np.asarray(Eobs).reshape(-1)[0]), dEobs_dm=dEobs_dm, dEobs_dS=dEobs_dS, Esde=Esde,
-                    Ef=out[1], Edf=out[2], dEdm=out[3], dEdS=out[4], m=mn, S=Sn)
+                    Ef=out[1], Edf=out[2], dEdm=out[3], dEdS=out[4], m=mn, S=Sn, tr_th=tr_th, tr_sig=tr_sig)
 
     def bwd(self, en, lam_last, Psi_last):
         s = self.sde
@@ -79,11 +84,25 @@ class OracleWindowOps:
             lam, Psi = lam.reshape(-1), Psi.reshape(-1)
         return _t(lam)[None], _t(Psi)[None]
 
-    def partial_energy(self, en):
-        part = en["Eobs"] + en["Esde"]
-        if self.window.rank == 0:
-            part += float(np.asarray(orc.kl0_gauss(self.m0, self.S0, self.full_sde)).reshape(-1)[0])
-        return torch.tensor([part], dtype=torch.float64)
+    def partial_sums(self, en):
+        self.n_th = en["tr_th"].size
+        return _t(np.concatenate(([en["Esde"], en["Eobs"]], en["tr_th"], en["tr_sig"])))[None]
+
+    def finish(self, sums):
+        s = sums.numpy()[0]
+        Esde, Eobs, tr_th, tr_sig = s[0], s[1], s[2:2 + self.n_th], s[2 + self.n_th:]
+        KL0 = float(np.asarray(orc.kl0_gauss(self.m0, self.S0, self.full_sde)).reshape(-1)[0])
+        sde = self.full_sde
+        if self.D == 1:                                   # sys_ornstein_uhlenbeck.py:153-156, sys_double_well.py:181-184
+            SigInv = 1.0 / float(np.asarray(sde["Sig"]).reshape(-1)[0])
+            dth = (1.0 if self.system == "ou" else 4.0) * SigInv * tr_th
+            dSig = np.array([-SigInv * Esde])
+        else:                                             # sys_lorenz_96_ut.py:250-256
+            SigInv = np.linalg.inv(sde["Sig"])
+            dth = np.diag(SigInv) * tr_th
+            dSig = -0.5 * SigInv.dot(np.diag(tr_sig)).dot(SigInv)
+        return dict(F=torch.tensor([KL0 + Eobs + Esde], dtype=torch.float64), Esde=_t([Esde]), Eobs=_t([Eobs]),
+                    dth=_t(dth)[None], dSig=_t(dSig)[None])
 
     def grad(self, en, m, S, lam, Psi):
         s = self.sde
@@ -127,7 +146,8 @@ def worker_time_sharded(rank, world, port, fixture, system, method, outdir):
         A, b = orc.unpack_Ab(g["Ab"], int(g["N"]), int(g["D"]))
         res = run_time_sharded(system, sde, m0, S0, A, b, batch.DistComm())
         np.savez(os.path.join(outdir, f"r{rank}.npz"), F=res.F.numpy(), gLA=res.gLA.numpy(), gLb=res.gLb.numpy(),
-                 m=res.m.numpy(), lam=res.lam.numpy(), t0=res.window.t0, t1=res.window.t1)
+                 m=res.m.numpy(), lam=res.lam.numpy(), t0=res.window.t0, t1=res.window.t1,
+                 dth=res.dth.numpy(), dSig=res.dSig.numpy())
     finally:
         dist.destroy_process_group()
 

@@ -95,6 +95,9 @@ def _check_against_unsharded(parts, ref, N, D):
     grad = np.concatenate((gLA.reshape(-1), gLb.reshape(-1)))
     for p in parts:
         assert relerr(float(np.asarray(p["F"]).reshape(-1)[0]), ref["F"]) < TOL
+        # the hyper-parameter gradients travel in the same all-reduce as the energies
+        assert relerr(np.asarray(p["dth"]).reshape(-1), np.asarray(ref["dEsde_dth"]).reshape(-1)) < TOL
+        assert relerr(np.asarray(p["dSig"]).reshape(-1), np.asarray(ref["dEsde_dSig"]).reshape(-1)) < TOL
     assert relerr(grad, ref["grad"].reshape(-1)) < TOL
     m = np.concatenate([np.asarray(p["m"])[0] for p in parts])
     lam = np.concatenate([np.asarray(p["lam"])[0] for p in parts])
@@ -106,7 +109,8 @@ def _check_against_unsharded(parts, ref, N, D):
 @pytest.mark.parametrize("system,fixture,world", [("l63", "sys_l63", 3), ("ou", "sys_ou", 2), ("l96_ut", "sys_l96_ut_d6", 4)])
 def test_time_windows_in_threads_equal_unsharded(system, fixture, world, method):
     out, ref, N, D = _threads_time_sharded(system, fixture, method, world)
-    parts = [dict(F=o.F.numpy(), gLA=o.gLA.numpy(), gLb=o.gLb.numpy(), m=o.m.numpy(), lam=o.lam.numpy()) for o in out]
+    parts = [dict(F=o.F.numpy(), gLA=o.gLA.numpy(), gLb=o.gLb.numpy(), m=o.m.numpy(), lam=o.lam.numpy(),
+                  dth=o.dth.numpy(), dSig=o.dSig.numpy()) for o in out]
     _check_against_unsharded(parts, ref, N, D)
 
 

@@ -232,3 +232,39 @@ def test_parameter_estimation_loop_batched():
         engine.make_problem(_lib.SYS_L63_UT, sde, m0, S0, P=1, theta=thetas[1:2]), dev(A0, 1), dev(b0, 1),
         rate=1e-3, nit=1, scg_nit=6, tol=0.0)
     assert relerr(one_update["theta"][0].cpu().numpy(), second) <= 1e-12
+
+
+def test_parameter_estimation_loop_vs_reference_run():
+    """Three updates of lorenz-63-parameter-estimation.py:189-277 recorded from the reference
+    (tests/golden/estimate_l63_ut.npz: the reference's smoothing, energy_mode and update):
+    the device loop must visit the same parameters, free energies and gradients."""
+    from vgpa_amd import engine, _lib
+    from vgpa_amd.auxiliary.estimate import estimate_parameters_batched
+    g = load_golden("estimate_l63_ut.npz")
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    N, D, P = int(g["N"]), int(g["D"]), 2
+    A0, b0 = orc.unpack_Ab(g["Ab"], N, D)
+    thetas = np.stack([g["thetas"][0] * np.array([1.05, 0.9, 1.0]), g["thetas"][0]])
+    dev = lambda x: engine.to_dev(np.broadcast_to(x, (P,) + x.shape))   # noqa: E731
+    prob = engine.make_problem(_lib.SYS_L63_UT, sde, m0, S0, P=P, theta=thetas)
+    out = estimate_parameters_batched(prob, dev(A0), dev(b0), rate=float(g["rate"]), nit=3,
+                                      scg_nit=int(g["scg_nit"]), tol=0.0)
+    assert relerr(out["thetas"][:, 1].cpu().numpy(), g["thetas"]) <= TOL
+    assert relerr(out["costs"][:, 1].cpu().numpy(), g["costs"]) <= TOL
+    assert relerr(out["grads"][:, 1].cpu().numpy(), g["grads"]) <= 1e-8
+    assert relerr(out["theta"][1].cpu().numpy(), g["thetas"][-1]) <= TOL
+
+
+def test_finite_differences_vs_reference_vector():
+    """finiteDiff(varFreeEnergy, x, mParam) recorded from the reference
+    (auxiliary/numerical.py:89-150, 984 evaluations) against the batched device version.
+    Each entry is a difference of two free energies of size 1e2 over 2e-6, so a relative
+    error of 1e-12 in F allows 1e-4 * 1e-12 / 1e-6 ... in absolute terms 1e-7."""
+    from vgpa_amd.auxiliary.numerical import finiteDiff
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    g = load_golden("finite_diff_l63.npz")
+    mParam = _facade_params("l63", g)
+    got = _quiet(finiteDiff, varFreeEnergy, np.array(g["Ab"], dtype=np.float64), mParam)
+    assert got.shape == g["finite_diff"].shape
+    assert np.abs(got - g["finite_diff"]).max() <= 1e-7

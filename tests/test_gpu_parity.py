@@ -14,7 +14,7 @@ TOL = 1e-9
 METHODS = ("EULER", "HEUN", "RK2", "RK4")
 SYSTEMS = [("ou", "sys_ou.npz"), ("dw", "sys_dw.npz"), ("l63", "sys_l63.npz"),
            ("l63_ut", "sys_l63_ut.npz"), ("l96_ut", "sys_l96_ut_d6.npz"),
-           ("l96_ut", "sys_l96_ut_d40.npz")]
+           ("l96_ut", "sys_l96_ut_d40.npz"), ("l96_ut", "sys_l96_ut_d16.npz")]
 
 
 def _dyn(system):
@@ -465,3 +465,16 @@ def test_observation_terms_with_dense_operators():
     assert abs(E - Er) <= TOL * abs(Er)
     assert relerr(dm, dmr) <= TOL and relerr(dS, dSr) <= TOL
     assert not dR.any()
+
+
+def test_observation_terms_dense_operators_vs_golden():
+    """core/likelihood.py@108-179 with a dense H and a non-diagonal R, recorded from the
+    reference."""
+    from vgpa_amd.core import likelihood
+    g = load_golden("likelihood_dense.npz")
+    sde = dict(D=int(g["D"]), N=int(g["N"]), dt=0.01, Rig=g["Rig"], H=g["H"], obsX=g["obsX"], obsY=g["obsY"],
+               theta=8.0, Sig=np.eye(int(g["D"])), ode_method="EULER")
+    E, dm, dS, dR = likelihood.gauss(g["m"], g["S"], sde)
+    assert abs(E - float(g["Eobs"])) <= TOL * abs(float(g["Eobs"]))
+    assert relerr(dm, g["dEobs_dm"]) <= TOL and relerr(dS, g["dEobs_dS"]) <= TOL
+    assert dR.shape == g["dEobs_dR"].shape and not dR.any()

@@ -62,6 +62,9 @@ def test_time_windows_on_device_vs_golden(name, world, method):
     Fref = float(g[f"{method}.F"])
     for r in range(world):
         assert abs(float(out[r][0].F.item()) - Fref) <= TOL * abs(Fref)
+        # the hyper-parameter gradients are part of the same all-reduce (every rank has them)
+        assert relerr(out[r][0].dth.cpu().numpy().reshape(-1), np.asarray(g[f"{method}.dEsde_dth"]).reshape(-1)) <= TOL
+        assert relerr(out[r][0].dSig.cpu().numpy().reshape(-1), np.asarray(g[f"{method}.dEsde_dSig"]).reshape(-1)) <= TOL
     gLA = torch.cat([out[r][0].gLA for r in range(world)], dim=1).cpu().numpy()
     gLb = torch.cat([out[r][0].gLb for r in range(world)], dim=1).cpu().numpy()
     grad = np.concatenate((gLA.reshape(-1), gLb.reshape(-1)))
@@ -87,12 +90,16 @@ def test_time_windows_batched_microbatches_match_unsharded_device():
     A = engine.to_dev(An[None] + 0.05 * rng.standard_normal((P, N, D, D)))
     b = engine.to_dev(bn[None] + 0.5 * rng.standard_normal((P, N, D)))
     prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P)
-    st = engine.free_energy(prob, A, b, want_edf=False)
+    st = engine.free_energy(prob, A, b, want_edf=False, want_hyper=True)
     gLA, gLb = engine.gradient(prob, A, b, st)
     out = _run_windows(_lib.SYS_L96_UT, sde, m0, S0, A, b, world=3, micro=2)
     for r in range(3):
         F = torch.cat([res.F for res in out[r]])
         assert relerr(F.cpu().numpy(), st.F.cpu().numpy()) <= 1e-12
+        dth = torch.cat([res.dth for res in out[r]])
+        dSig = torch.cat([res.dSig for res in out[r]])
+        assert relerr(dth.cpu().numpy(), st.dth.cpu().numpy()) <= 1e-12
+        assert relerr(dSig.cpu().numpy(), st.dSig.cpu().numpy()) <= 1e-12
     got_A = torch.cat([torch.cat([res.gLA for res in out[r]], dim=0) for r in range(3)], dim=1)
     got_b = torch.cat([torch.cat([res.gLb for res in out[r]], dim=0) for r in range(3)], dim=1)
     assert relerr(got_A.cpu().numpy(), gLA.cpu().numpy()) <= 1e-12

@@ -155,3 +155,42 @@ def test_backtrack_and_cg_minimise_a_quadratic():
     assert eta == 0.15 and cnt == 1
     x, fx, _, stat = _quiet(optimize.optim_CG, f, np.array([1.0, -2.0, 0.5]), gf, dict(nit=200), {})
     assert fx < 1e-3 and stat["f_eval"] > stat["g_eval"]
+
+
+def test_estimation_loop_replays_the_recorded_reference_run():
+    """Three updates of the drift-parameter loop of lorenz-63-parameter-estimation.py:189-277,
+    recorded from the reference (its smoothing, its energy_mode, its update): the loop logic of
+    estimate_parameters_batched, driven by the oracle, must visit the same parameters, free
+    energies and gradients.  The second problem starts elsewhere and must not disturb it."""
+    from vgpa_amd.auxiliary.estimate import estimate_parameters_batched
+    g = load_golden("estimate_l63_ut.npz")
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    N, D, P = int(g["N"]), int(g["D"]), 2
+    A0, b0 = orc.unpack_Ab(g["Ab"], N, D)
+    scg_nit = int(g["scg_nit"])
+
+    class OracleOps:
+        def _sdes(self, theta):
+            return [dict(sde, theta=theta[p].numpy().copy()) for p in range(P)]
+
+        def smooth(self, theta, A, b):
+            ev = _batched_evaluator("l63_ut", self._sdes(theta), m0, S0, N, D)
+            return optimize.scg_batched(None, A, b, nit=scg_nit, evaluate=ev)[:3]
+
+        def dth(self, theta, A, b):
+            rows = []
+            for p, s in enumerate(self._sdes(theta)):
+                Ab = np.concatenate((A[p].numpy().ravel(), b[p].numpy().ravel()))
+                rows.append(np.asarray(orc.evaluate("l63_ut", Ab, m0, S0, s, with_grad=False)["dEsde_dth"]).ravel())
+            return torch.from_numpy(np.stack(rows))
+
+    theta0 = torch.from_numpy(np.stack([g["thetas"][0], g["thetas"][0] * np.array([1.05, 0.9, 1.0])]))
+    A = torch.from_numpy(np.broadcast_to(A0, (P,) + A0.shape).copy())
+    b = torch.from_numpy(np.broadcast_to(b0, (P,) + b0.shape).copy())
+    out = estimate_parameters_batched(None, A, b, rate=float(g["rate"]), nit=3, scg_nit=scg_nit, tol=0.0,
+                                      ops=OracleOps(), theta0=theta0)
+    assert relerr(out["thetas"][:, 0].numpy(), g["thetas"]) <= 1e-9
+    assert relerr(out["costs"][:, 0].numpy(), g["costs"]) <= 1e-9
+    assert relerr(out["grads"][:, 0].numpy(), g["grads"]) <= 1e-8
+    assert relerr(out["thetas"][-1, 1].numpy(), g["thetas"][-1]) > 1e-3

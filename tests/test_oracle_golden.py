@@ -10,7 +10,7 @@ from oracle import vgpa_oracle as orc
 TOL = 1e-12
 SYSTEMS = [("ou", "sys_ou.npz"), ("dw", "sys_dw.npz"), ("l63", "sys_l63.npz"),
            ("l63_ut", "sys_l63_ut.npz"), ("l96_ut", "sys_l96_ut_d6.npz"),
-           ("l96_ut", "sys_l96_ut_d40.npz")]
+           ("l96_ut", "sys_l96_ut_d40.npz"), ("l96_ut", "sys_l96_ut_d16.npz")]
 
 
 @pytest.mark.parametrize("system,fname", SYSTEMS)
@@ -115,3 +115,24 @@ def test_unknown_method_raises():
     m0, S0 = initial_moments(g)
     with pytest.raises(ValueError, match="Unknown method of integration"):
         orc.evaluate("ou", g["Ab"], m0, S0, sde)
+
+
+def test_observation_terms_dense_operators():
+    """core/likelihood.py@108-179 with a dense H and a non-diagonal R."""
+    g = load_golden("likelihood_dense.npz")
+    sde = dict(D=int(g["D"]), N=int(g["N"]), dt=0.01, Rig=g["Rig"], H=g["H"], obsX=g["obsX"], obsY=g["obsY"])
+    Eobs, dm, dS = orc.likelihood_gauss(g["m"], g["S"], sde)
+    assert relerr(Eobs, g["Eobs"]) <= TOL
+    assert relerr(dm, g["dEobs_dm"]) <= TOL and relerr(dS, g["dEobs_dS"]) <= TOL
+    assert not g["dEobs_dR"].any()
+
+
+def test_finite_differences_vs_reference():
+    """auxiliary/numerical.py:89-150 on the analytic Lorenz-63 fixture.  A difference of two
+    free energies of size 1e2 over 2e-6: absolute agreement to 1e-7."""
+    g = load_golden("finite_diff_l63.npz")
+    sde = sde_from_golden(g)
+    m0, S0 = initial_moments(g)
+    got = orc.finite_diff(lambda x: orc.evaluate("l63", x, m0, S0, sde, with_grad=False)["F"], g["Ab"])
+    assert got.shape == g["finite_diff"].shape
+    assert np.abs(got - g["finite_diff"]).max() <= 1e-7

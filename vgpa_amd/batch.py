@@ -15,10 +15,13 @@ on ROCm; ``gloo`` serves the CPU tests):
   receives (m, S) of row t0, integrates to its halo row t1 and sends that row on.
   The per-step energy kernel, the observation terms and the gradient assembly are
   local.  The backward scan is handed the other way: rank g receives (lam, Psi) of
-  its halo row, integrates down to row t0 and sends that row back.  The energy is
-  the sum of the windows' partial sums: one ``all_reduce``.  Splitting the batch of
-  problems into micro-batches pipelines the hand-offs, so that rank g+1 scans
-  micro-batch c while rank g already scans c+1.
+  its halo row, integrates down to row t0 and sends that row back.  The energies and
+  the hyper-parameter gradients are sums of the windows' partial sums: one
+  ``all_reduce`` of [Esde, Eobs, integral of the dEsde/dtheta integrand, integral of
+  the dEsde/dSigma integrand] per problem (2 + 2 D doubles for the Lorenz systems;
+  the trapezoid weights are those of the global segmentation, so the partial sums
+  add exactly).  Splitting the batch of problems into micro-batches pipelines the
+  hand-offs, so that rank g+1 scans micro-batch c while rank g already scans c+1.
 
 The kernels themselves are reached through an *ops* object (``DeviceWindowOps``
 here); the window logic only moves tensors, which is what lets the CPU tests drive
@@ -103,6 +106,9 @@ class DistComm:
         return r if self._group is None else self._dist.get_global_rank(self._group, r)
 
     def send(self, dst, tensors):
+        # completed sends release their staging buffers here, so that a long run of
+        # micro-batches does not keep every message alive until flush()
+        self._pending = [(w, b) for w, b in self._pending if not w.is_completed()]
         buf = torch.cat([t.reshape(-1) for t in tensors]).contiguous()
         self._pending.append((self._dist.isend(buf, self._global(dst), group=self._group), buf))
 
@@ -228,7 +234,9 @@ def evaluate_problem_shard(evaluate, P_total, comm, gather=True):
 @dataclass
 class WindowResult:
     """One rank's share of a time-sharded evaluation.  Per-step arrays hold the
-    owned rows only; F is the complete free energy on every rank."""
+    owned rows only; F, Esde, Eobs and the hyper-parameter gradients dth, dSig
+    (dynamics/sys_lorenz_96_ut.py:250-256) are those of the whole time axis, on every
+    rank (dth, dSig are None when the ops object was built without hyper-gradients)."""
     F: torch.Tensor
     m: torch.Tensor
     S: torch.Tensor
@@ -237,6 +245,10 @@ class WindowResult:
     gLA: Optional[torch.Tensor]
     gLb: Optional[torch.Tensor]
     window: TimeWindow
+    Esde: Optional[torch.Tensor] = None
+    Eobs: Optional[torch.Tensor] = None
+    dth: Optional[torch.Tensor] = None
+    dSig: Optional[torch.Tensor] = None
 
 
 def free_energy_time_sharded(ops_list, comm, want_grad=True) -> List[WindowResult]:
@@ -252,7 +264,12 @@ def free_energy_time_sharded(ops_list, comm, want_grad=True) -> List[WindowResul
         fwd(m_first, S_first)   -> m, S over the local rows (halo included)
         energy_and_obs(m, S)    -> opaque bundle; its partial energies over owned rows
         bwd(bundle, lam_last, Psi_last) -> lam, Psi over the local rows (None = zero start)
-        partial_energy(bundle)  -> (P,) Eobs + Esde of the owned rows (+ KL0 on rank 0)
+        partial_sums(bundle)    -> (P, K) sums over the owned rows: column 0 Esde, column 1
+                                   Eobs, then the time integrals of the dEsde/dtheta and
+                                   dEsde/dSigma integrands (absent without hyper-gradients)
+        finish(sums)            -> dict(F, Esde, Eobs, dth, dSig) from the all-reduced sums
+                                   (adds KL0, which every rank can evaluate, and scales the
+                                   hyper-gradient integrals)
         grad(bundle, m, S, lam, Psi) -> gLA, gLb over the local rows
     """
     rank, world = comm.rank, comm.world
@@ -282,19 +299,21 @@ def free_energy_time_sharded(ops_list, comm, want_grad=True) -> List[WindowResul
             comm.send(rank - 1, [lam[:, 0], Psi[:, 0]])
         bwd_out.append((lam, Psi))
     # One collective for all micro-batches.
-    parts = [ops.partial_energy(bundle) for ops, bundle in zip(ops_list, bundles)]
+    parts = [ops.partial_sums(bundle) for ops, bundle in zip(ops_list, bundles)]
     sizes = [int(p.numel()) for p in parts]
     total = comm.all_reduce_sum(torch.cat([p.reshape(-1) for p in parts]))
-    Fs = torch.split(total, sizes)
+    sums = [t.reshape(p.shape) for t, p in zip(torch.split(total, sizes), parts)]
     results = []
-    for ops, bundle, (m, S), (lam, Psi), F in zip(ops_list, bundles, fwd_out, bwd_out, Fs):
+    for ops, bundle, (m, S), (lam, Psi), sm in zip(ops_list, bundles, fwd_out, bwd_out, sums):
         gLA = gLb = None
         n = ops.window.owned
         if want_grad:
             gLA, gLb = ops.grad(bundle, m, S, lam, Psi)
             gLA, gLb = gLA[:, :n], gLb[:, :n]
-        results.append(WindowResult(F=F, m=m[:, :n], S=S[:, :n], lam=lam[:, :n], Psi=Psi[:, :n],
-                                    gLA=gLA, gLb=gLb, window=ops.window))
+        fin = ops.finish(sm)
+        results.append(WindowResult(F=fin["F"], m=m[:, :n], S=S[:, :n], lam=lam[:, :n], Psi=Psi[:, :n],
+                                    gLA=gLA, gLb=gLb, window=ops.window, Esde=fin["Esde"], Eobs=fin["Eobs"],
+                                    dth=fin.get("dth"), dSig=fin.get("dSig")))
     comm.flush()
     return results
 
@@ -322,10 +341,12 @@ class DeviceWindowOps:
     """The HIP kernels on one rank's rows.  A, b: device tensors over the local rows
     (``window.local_slice()`` of the full arrays), leading axis P."""
 
-    def __init__(self, system, sde, m0, S0, window, A_rows, b_rows, P=1, theta=None, want_edf=False):
+    def __init__(self, system, sde, m0, S0, window, A_rows, b_rows, P=1, theta=None, want_edf=False,
+                 want_hyper=True):
         from . import engine
         self._e = engine
         self.window = window
+        self.want_hyper = bool(want_hyper) and system >= 0
         local_sde, w = local_window_sde(sde, window)
         self.prob = engine.make_problem(system, local_sde, m0, S0, P=P, theta=theta)
         self.prob.w = engine.to_dev(w)
@@ -351,7 +372,7 @@ class DeviceWindowOps:
         p, e = self.prob, self._e
         Eobs, dEobs_dm, jumpS = e.obs_terms(p, m, S)
         en = e.energy_terms(p.system, self.A, self.b, m, S, p.SigInv, p.sig_inv_diag, p.theta, p.w, p.dt,
-                            want_hyper=False, want_edf=self.want_edf)
+                            want_hyper=self.want_hyper, want_edf=self.want_edf)
         en.update(Eobs=Eobs, dEobs_dm=dEobs_dm, jumpS=jumpS)
         return en
 
@@ -363,9 +384,27 @@ class DeviceWindowOps:
         return e.bwd_scan(p.method, self.A, en["dEdm"], en["dEdS"], en["dEobs_dm"], p.dt, obs_flag=p.obs_flag,
                           jumpS=en["jumpS"], symmetric=sym, lam_last=lam_last, Psi_last=Psi_last)
 
-    def partial_energy(self, en):
-        part = en["Eobs"] + en["Esde"]
-        return part + self._e.kl0(self.prob) if self.window.rank == 0 else part
+    def partial_sums(self, en):
+        P = self.prob.P
+        cols = [en["Esde"].reshape(P, 1), en["Eobs"].reshape(P, 1)]
+        if self.want_hyper:
+            cols.append(en["tr_th"].reshape(P, -1))
+            if en["tr_sig"] is not None:
+                cols.append(en["tr_sig"].reshape(P, -1))
+        return torch.cat(cols, dim=1)
+
+    def finish(self, sums):
+        p, e = self.prob, self._e
+        Esde, Eobs = sums[:, 0].contiguous(), sums[:, 1].contiguous()
+        out = dict(Esde=Esde, Eobs=Eobs, F=e.kl0(p) + Eobs + Esde)      # core/varFreeEnergy.py:111
+        if self.want_hyper:
+            if p.D == 1:
+                tr_th, tr_sig = sums[:, 2], None
+            else:
+                n_th = (sums.shape[1] - 2) // 2
+                tr_th, tr_sig = sums[:, 2:2 + n_th], sums[:, 2 + n_th:]
+            out["dth"], out["dSig"] = e.hyper_gradients(p.system, p.D, p.SigInv, p.sig_inv_diag, Esde, tr_th, tr_sig)
+        return out
 
     def grad(self, en, m, S, lam, Psi):
         return self._e.grad_assemble(self.prob, self.A, self.b, m, S, lam, Psi, en["Ef"], en["Edf"])

@@ -404,22 +404,30 @@ def init_ab0(mt0, sig_diag, s0_diag, dt):
 # ---------------------------------------------------------------------------
 # the evaluation
 # ---------------------------------------------------------------------------
+def hyper_gradients(system, D, SigInv, sig_inv_diag, Esde, tr_th, tr_sig):
+    """dEsde/dtheta and dEsde/dSigma from the time integrals of the per-step integrands
+    (dynamics/sys_lorenz_96_ut.py:250-256, sys_lorenz_63_ut.py:258-264,
+    sys_ornstein_uhlenbeck.py:153-156, sys_double_well.py:181-184).  Linear in the
+    integrals, so sums of time-window partial integrals give the same result."""
+    if D == 1:
+        k = 1.0 if system == _lib.SYS_OU else 4.0
+        return k * SigInv.reshape(-1) * tr_th, -SigInv.reshape(-1) * Esde
+    return sig_inv_diag * tr_th, -0.5 * SigInv @ torch.diag_embed(tr_sig) @ SigInv
+
+
 def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hyper=True, want_edf=True):
     """The ``energy_mode`` contract on device: per-step kernel + time reductions.
-    Returns a dict with Esde (P,), Ef, Edf, dEdm, dEdS, dth, dSig, status."""
+    Returns a dict with Esde (P,), Ef, Edf, dEdm, dEdS, dth, dSig, status; with
+    ``want_hyper`` also the raw time integrals tr_th, tr_sig the hyper-gradients are
+    formed from (what time windows add up)."""
     D = 1 if A.dim() == 2 else A.shape[-1]
     out = esde(system, A, b, m, S, sig_inv_diag, theta, want_edf, want_hyper)
     out["Esde"] = reduce_energy(out["Esde_t"], w, dt)
     if want_hyper:
-        tr_th = reduce_energy(out["dth_t"], w, dt)
-        if D == 1:
-            k = 1.0 if system == _lib.SYS_OU else 4.0
-            out["dth"] = k * SigInv.reshape(-1) * tr_th                      # sys_ornstein_uhlenbeck.py:153
-            out["dSig"] = -SigInv.reshape(-1) * out["Esde"]                  # :156
-        else:
-            out["dth"] = sig_inv_diag * tr_th                                # sys_lorenz_96_ut.py:253
-            tr_sig = reduce_energy(out["dSig_t"], w, dt)
-            out["dSig"] = -0.5 * SigInv @ torch.diag_embed(tr_sig) @ SigInv  # :256
+        out["tr_th"] = reduce_energy(out["dth_t"], w, dt)
+        out["tr_sig"] = reduce_energy(out["dSig_t"], w, dt) if D > 1 else None
+        out["dth"], out["dSig"] = hyper_gradients(system, D, SigInv, sig_inv_diag, out["Esde"], out["tr_th"],
+                                                  out["tr_sig"])
     return out
 
 
