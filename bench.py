@@ -3,34 +3,45 @@
 
 Workload (BASELINE.json metric): Lorenz-96, D = 40, T = 10, dt = 0.005 (N = 2002
 time points), unscented-transform expectations, Euler integrators; a batch of P
-independent problems per GPU (parameter-grid points), synthetic inputs resident
-in HBM.  One "step" = varFreeEnergy + gradL_Ab for the whole batch:
-forward scan, observation terms, per-step energy kernel, time reductions,
-backward scan, gradient assembly.  value = P_total * N * steps / time.
+independent problems (parameter-grid points), synthetic inputs resident in HBM.
+One "step" = varFreeEnergy + gradL_Ab for the whole batch: forward scan,
+observation terms, per-step energy kernel, time reductions, backward scan,
+gradient assembly.  value = P_total * N * steps / time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--problems P] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode problems|windows]
+                  [--problems P] [--micro M] [--no-cpu]
 
-For N > 1 launch under torch.distributed.run (one rank per GPU); problems are
-sharded across ranks with no data-path collective (weak scaling: P per GPU fixed).
+--mode problems (default): P problems PER GPU, sharded by problem across the ranks
+  (vgpa_amd.batch.evaluate_problem_shard): no data-path collective, one all_gather of
+  the P_total free energies per step.  Weak scaling.
+--mode windows: P problems IN ALL, every one cut into --gpus contiguous time windows
+  (vgpa_amd.batch.free_energy_time_sharded): scan boundary rows handed between
+  neighbouring ranks, one all_reduce of the energy and hyper-gradient partial sums per
+  step, M micro-batches of problems to pipeline the hand-offs.  Strong scaling.
+
+For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false>"
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
 
 
 def synth_problem(D, N, dt, P, seed, dev):
     """Synthetic inputs of the benchmark shape, generated on the device."""
+    import torch
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     a0 = 0.5 * 4.0 / 0.25
@@ -49,41 +60,86 @@ def synth_problem(D, N, dt, P, seed, dev):
     return A, b, sde, mu0 + 0.1, 0.25 * np.eye(D), thetas
 
 
-def cpu_baseline(D, dt, seconds_target=12.0):
-    """The NumPy oracle (a port of the reference algorithm, one process, BLAS
-    threads as configured on the host) on a bounded sample of the same workload:
-    one problem, as many time steps as fit the time budget."""
-    from oracle import vgpa_oracle as orc
-    rng = np.random.default_rng(1)
-    threads = 1
+# ---------------------------------------------------------------------------
+# CPU baseline: the NumPy oracle, one process per core of this job's CPU share
+# ---------------------------------------------------------------------------
+def _cpu_worker(args):
+    """One problem of the benchmark shape with n time steps, `repeat` evaluations."""
+    D, dt, n, seed, repeat = args
     try:
         from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
+        threadpool_limits(limits=1)
     except Exception:   # pragma: no cover
-        limiter = None
-    n = 64
-    best = None
-    while True:
-        A = 8.0 * np.eye(D)[None] + 0.1 * rng.standard_normal((n, D, D))
-        b = 5.0 * rng.standard_normal((n, D))
-        obsX = np.arange(4, n, 8)
-        mu0 = rng.standard_normal(D)
-        sde = dict(Sig=4.0 * np.eye(D), theta=8.0, Rig=np.eye(D), D=D, N=n, H=np.eye(D), obsX=obsX,
-                   obsY=3.0 * rng.standard_normal((obsX.size, D)), px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)),
-                   dt=dt, ode_method="EULER")
-        Ab = np.concatenate((A.ravel(), b.ravel()))
-        t0 = time.perf_counter()
+        pass
+    from oracle import vgpa_oracle as orc
+    rng = np.random.default_rng(seed)
+    A = 8.0 * np.eye(D)[None] + 0.1 * rng.standard_normal((n, D, D))
+    b = 5.0 * rng.standard_normal((n, D))
+    obsX = np.arange(4, n, 8)
+    mu0 = rng.standard_normal(D)
+    sde = dict(Sig=4.0 * np.eye(D), theta=8.0, Rig=np.eye(D), D=D, N=n, H=np.eye(D), obsX=obsX,
+               obsY=3.0 * rng.standard_normal((obsX.size, D)), px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)),
+               dt=dt, ode_method="EULER")
+    Ab = np.concatenate((A.ravel(), b.ravel()))
+    t0 = time.perf_counter()
+    for _ in range(repeat):
         orc.evaluate("l96_ut", Ab, mu0 + 0.1, 0.25 * np.eye(D), sde)
-        el = time.perf_counter() - t0
-        best = dict(value=n / el, unit="problem*timesteps/s", cores=threads, kind="port",
-                    sample=f"1 problem x {n} time steps of the same Lorenz-96 D={D} evaluation, "
-                           f"NumPy oracle, 1 BLAS thread, {el:.1f} s")
-        if el * 4 > seconds_target or n >= 2002:
-            break
-        n = min(2002, n * 4)
-    if limiter is not None:
-        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    return best
+    return time.perf_counter() - t0
+
+
+def cpu_share():
+    """Cores this job may use: the thread budget the environment sets for the box
+    (os.cpu_count() shows the whole machine there), else what the scheduler allows."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:   # pragma: no cover
+        avail = os.cpu_count() or 1
+    budget = os.environ.get("VGPA_BENCH_CORES") or os.environ.get("OMP_NUM_THREADS")
+    n = int(budget) if budget and budget.isdigit() and int(budget) > 0 else avail
+    return max(1, min(n, avail))
+
+
+def cpu_baseline(D, dt, seconds_target=12.0):
+    """The NumPy oracle (a port of the reference algorithm) on a bounded sample of the same
+    workload: one process per core, each with one BLAS thread and its own problem of n time
+    steps, n sized so that the sample takes about `seconds_target` seconds.  Started before
+    anything touches the GPU (worker processes are spawned)."""
+    import multiprocessing as mp
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"        # inherited by the workers
+    cores = cpu_share()
+    t_cal = _cpu_worker((D, dt, 64, 1, 1))          # calibration in this process
+    n = int(min(2002, max(64, 64 * seconds_target / max(t_cal, 1e-3))))
+    repeat = max(1, int(seconds_target / max(t_cal * n / 64.0, 1e-3)))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        times = pool.map(_cpu_worker, [(D, dt, n, 100 + c, repeat) for c in range(cores)])
+    wall = time.perf_counter() - t0
+    rate = float(sum(repeat * n / t for t in times))
+    return dict(value=rate, unit="problem*timesteps/s", cores=cores, kind="port",
+                per_core=rate / cores,
+                sample=f"{cores} processes x 1 problem x {n} time steps x {repeat} evaluation(s) of the same "
+                       f"Lorenz-96 D={D} free energy + gradient, NumPy oracle, 1 BLAS thread each, "
+                       f"{max(times):.1f} s of work per process ({wall:.1f} s wall incl. start-up)")
+
+
+def measured_traffic_per_unit(kernel):
+    """HBM bytes per (problem, time step) of `kernel` from the tracked rocprofv3 counter
+    summary (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for 16-byte-per-lane
+    reads): the last line of profiles/pmc_hbm_traffic.txt whose first field is the kernel
+    name.  None when the file has no line for this kernel."""
+    try:
+        lines = open(TRAFFIC_FILE).read().splitlines()
+    except OSError:
+        return None
+    found = None
+    for ln in lines:
+        if ln.startswith("#") or "," not in ln:
+            continue
+        m = re.match(r"^(.*),([0-9.e+]+),([0-9.e+]+),([0-9.e+]+),([0-9.e+]+),([0-9.e+]+),([0-9.e+]+),([0-9.e+]+)$", ln)
+        if m and m.group(1).strip() == kernel:
+            found = float(m.group(7))
+    return found
 
 
 def main():
@@ -91,7 +147,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--problems", type=int, default=512, help="problems per GPU")
+    ap.add_argument("--mode", choices=("problems", "windows"), default="problems")
+    ap.add_argument("--problems", type=int, default=512,
+                    help="problems per GPU (mode problems) or in all (mode windows)")
+    ap.add_argument("--micro", type=int, default=4, help="micro-batches of problems (mode windows)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -100,6 +159,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    D, N, dt, P = 40, 2002, 0.005, args.problems
+
+    cpu = None
+    if not args.no_cpu and world == 1 and rank == 0:
+        cpu = cpu_baseline(D, dt)          # before the GPU is initialised
+
+    import torch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -107,14 +173,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from vgpa_amd import engine, _lib
-
-    D, N, dt, P = 40, 2002, 0.005, args.problems
-    A, b, sde, m0, S0, thetas = synth_problem(D, N, dt, P, 20240 + rank, dev)
-    prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
+    from vgpa_amd import batch, engine, _lib
+    comm = batch.DistComm() if world > 1 else batch.SingleComm()
 
     events = {k: [] for k in ("fwd_scan", "esde", "bwd_scan", "grad_assemble")}
-    sym_bwd = prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D)
 
     def timed_call(name, timed, fn):
         """Run fn between two HIP events recorded on the stream the kernels are launched on
@@ -128,20 +190,52 @@ def main():
         events[name].append((e0, e1))
         return out
 
-    def step(timed):
-        m, S = timed_call("fwd_scan", timed, lambda: engine.fwd_scan(
-            prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd))
-        Eobs, dEobs_dm, jumpS = engine.obs_terms(prob, m, S)
-        en = timed_call("esde", timed, lambda: engine.esde(
-            prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
-        Esde = engine.reduce_energy(en["Esde_t"], prob.w, prob.dt)
-        lam, Psi = timed_call("bwd_scan", timed, lambda: engine.bwd_scan(
-            prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-            obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym_bwd))
-        F = engine.kl0(prob) + Eobs + Esde
-        gLA, gLb = timed_call("grad_assemble", timed, lambda: engine.grad_assemble(
-            prob, A, b, m, S, lam, Psi, en["Ef"], en["Edf"]))
-        return F, gLA, gLb, en["status"]
+    if args.mode == "problems":
+        P_total = world * P
+        lo, hi = batch.shard_bounds(P_total, rank, world)
+        A, b, sde, m0, S0, thetas = synth_problem(D, N, dt, hi - lo, 20240 + rank, dev)
+        prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=hi - lo, theta=thetas)
+        sym_bwd = prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D)
+        units_per_launch = (hi - lo) * N
+
+        def evaluate_block(timed):
+            m, S = timed_call("fwd_scan", timed, lambda: engine.fwd_scan(
+                prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd))
+            Eobs, dEobs_dm, jumpS = engine.obs_terms(prob, m, S)
+            en = timed_call("esde", timed, lambda: engine.esde(
+                prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
+            Esde = engine.reduce_energy(en["Esde_t"], prob.w, prob.dt)
+            lam, Psi = timed_call("bwd_scan", timed, lambda: engine.bwd_scan(
+                prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
+                obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym_bwd))
+            F = engine.kl0(prob) + Eobs + Esde
+            gLA, gLb = timed_call("grad_assemble", timed, lambda: engine.grad_assemble(
+                prob, A, b, m, S, lam, Psi, en["Ef"], en["Edf"]))
+            return F, (gLA, gLb, en["status"])
+
+        def step(timed):
+            # gradients stay on the owning GPU; the free energies of the whole grid are gathered
+            F_all, extras, _ = batch.evaluate_problem_shard(lambda lo_, hi_: evaluate_block(timed), P_total, comm)
+            return F_all, extras[2]
+    else:
+        P_total = P
+        win = batch.time_window(N, rank, world)
+        micro = max(1, min(args.micro, P))
+        sde = None
+        ops = []
+        for c in range(micro):
+            plo, phi = batch.shard_bounds(P, c, micro)
+            # every rank draws the same problems (same seed) and keeps its rows
+            A, b, sde, m0, S0, thetas = synth_problem(D, N, dt, phi - plo, 20240 + c, dev)
+            sl = win.local_slice()
+            ops.append(batch.DeviceWindowOps(_lib.SYS_L96_UT, sde, m0, S0, win, A[:, sl].contiguous(),
+                                             b[:, sl].contiguous(), P=phi - plo, theta=thetas, want_hyper=True))
+            del A, b
+        units_per_launch = None   # several launches per kernel and step: per-kernel timing is not split out
+
+        def step(timed):
+            res = batch.free_energy_time_sharded(ops, comm)
+            return torch.cat([r.F for r in res]), None
 
     def barrier():
         torch.cuda.synchronize()
@@ -161,48 +255,64 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    F, gLA, gLb, status = out
-    ok = bool(torch.isfinite(F).all().item()) and int(status.max().item()) == 0
-    kernel_ms = {k: float(np.mean([a.elapsed_time(b_) for a, b_ in v])) for k, v in events.items()}
-    esde_ms = kernel_ms["esde"]
+    F, status = out
+    ok = bool(torch.isfinite(F).all().item()) and int(F.numel()) == P_total
+    if status is not None:
+        ok = ok and int(status.max().item()) == 0
 
     if rank == 0:
-        total_units = world * P * N * args.steps
-        bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
-        achieved = P * N * bytes_per_unit / (esde_ms * 1e-3) / 1e9
-        # Algorithmic bytes per (problem, time step) of the other three kernels: forward scan reads
-        # A, b and writes m, S; backward scan reads A, dEsde_dS, dEsde_dm, jumps and writes lam, Psi;
-        # gradient assembly reads A, S, Psi and the vectors and writes dL/dA, dL/db.
-        per_unit = {"fwd_scan": 8 * (2 * D * D + 2 * D), "esde": bytes_per_unit,
-                    "bwd_scan": 8 * (3 * D * D + 3 * D), "grad_assemble": 8 * (4 * D * D + 6 * D)}
-        kernels = {k: {"avg_ms": kernel_ms[k], "bytes_per_unit": per_unit[k],
-                       "achieved_GBps": P * N * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9,
-                       "frac": P * N * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                   for k in kernel_ms}
-        # HBM bytes per unit measured with rocprofv3 PMC counters (FETCH_SIZE doubled for the
-        # 16-byte-per-lane reads, WRITE_SIZE as reported) in separate passes at 256 problems:
-        # profiles/r1_pmc_hbm_traffic.txt.  Scaled by the units of this launch.
-        measured_traffic_per_unit = 39873
+        total_units = P_total * N * args.steps
+        value = total_units / elapsed
         line = {
             "metric": "free-energy+grad evals/sec (problems x timesteps), L96 D=40",
-            "value": total_units / elapsed,
+            "value": value,
             "unit": "problem*timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
-                                   f"{P} problems per GPU (theta grid), F + dL/dA, dL/db",
-                       "problems_per_gpu": P, "N": N, "D": D, "sharding": f"problems x{world}"},
+            "higher_is_better": True, "scaling": "weak" if args.mode == "problems" else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "valid": ok,
-            "roofline": {"kernel": "esde_l96_ut_wave40_kernel<false>", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic_per_unit * P * N, "bytes_per_unit": bytes_per_unit,
-                         "avg_ms": esde_ms},
-            "kernels": kernels,
         }
-        if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(D, dt)
+        # whole evaluation against the contract minimum: inputs A, b once, every contract output
+        # (m, S, lam, Psi, dL/dA, dL/db ...) once = 8 (5 D^2 + 5 D) bytes per (problem, time step)
+        e2e_bytes = 8 * (5 * D * D + 5 * D)
+        e2e = value / world * e2e_bytes / 1e9
+        line["end_to_end"] = {"bytes_per_unit": e2e_bytes, "achieved_GBps_per_gpu": e2e, "frac": e2e / HBM_PEAK_GBS}
+        if args.mode == "problems":
+            line["config"] = {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
+                                          f"{P} problems per GPU (theta grid), F + dL/dA, dL/db",
+                              "problems_per_gpu": P, "N": N, "D": D, "sharding": f"problems x{world}",
+                              "collective": "all_gather of F" if world > 1 else "none (1 rank)"}
+            kernel_ms = {k: float(np.mean([a.elapsed_time(b_) for a, b_ in v])) for k, v in events.items()}
+            esde_ms = kernel_ms["esde"]
+            bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
+            achieved = units_per_launch * bytes_per_unit / (esde_ms * 1e-3) / 1e9
+            # Algorithmic bytes per (problem, time step) of the other three kernels: forward scan reads
+            # A, b and writes m, S; backward scan reads A, dEsde_dS, dEsde_dm, jumps and writes lam, Psi;
+            # gradient assembly reads A, S, Psi and the vectors and writes dL/dA, dL/db.
+            per_unit = {"fwd_scan": 8 * (2 * D * D + 2 * D), "esde": bytes_per_unit,
+                        "bwd_scan": 8 * (3 * D * D + 3 * D), "grad_assemble": 8 * (4 * D * D + 6 * D)}
+            kernels = {k: {"avg_ms": kernel_ms[k], "bytes_per_unit": per_unit[k],
+                           "achieved_GBps": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9,
+                           "frac": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                       for k in kernel_ms}
+            traffic_unit = measured_traffic_per_unit(ESDE_KERNEL)
+            line["roofline"] = {"kernel": ESDE_KERNEL, "bound": "hbm", "achieved": achieved,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                "traffic": None if traffic_unit is None else traffic_unit * units_per_launch,
+                                "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if traffic_unit is not None else None,
+                                "bytes_per_unit": bytes_per_unit, "avg_ms": esde_ms}
+            line["kernels"] = kernels
+        else:
+            line["config"] = {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
+                                          f"{P} problems, each cut into {world} time windows, F + dL/dA, dL/db "
+                                          "+ dEsde/dtheta, dEsde/dSigma",
+                              "problems": P, "micro_batches": len(ops), "N": N, "D": D,
+                              "sharding": f"time windows x{world}",
+                              "collective": "all_reduce of (2 + 2 D) partial sums per problem; "
+                                            "point-to-point scan boundary rows"}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
