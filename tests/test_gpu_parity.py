@@ -478,3 +478,62 @@ def test_observation_terms_dense_operators_vs_golden():
     assert abs(E - float(g["Eobs"])) <= TOL * abs(float(g["Eobs"]))
     assert relerr(dm, g["dEobs_dm"]) <= TOL and relerr(dS, g["dEobs_dS"]) <= TOL
     assert dR.shape == g["dEobs_dR"].shape and not dR.any()
+
+
+def test_lorenz96_fallback_without_a_status_array_and_symmetric_output():
+    """The C entry point documents `status` as optional: the D = 40 kernel must redo the
+    steps that are not positive definite without it too (same bits as with it), and the
+    redone steps must be exactly symmetric like the regular ones."""
+    import torch
+    from vgpa_amd import engine, _lib
+    g = load_golden("l96_ut_nonpd_d40.npz")
+    sde = sde_from_golden(g)
+    N, D = sde["N"], sde["D"]
+    A, b = orc.unpack_Ab(g["Ab"], N, D)
+    d = engine.to_dev
+    Ad, bd, md, Sd = d(A[None]), d(b[None]), d(g["m"][None]), d(g["S"][None])
+    sid = d(1.0 / np.diag(sde["Sig"]))
+    th = d(np.array([float(sde["theta"])]))
+    with_status = engine.esde(_lib.SYS_L96_UT, Ad, bd, md, Sd, sid, th, want_edf=False, want_hyper=True)
+    assert int((with_status["status"] & _lib.ST_CHOL_FALLBACK).sum().item()) == len(range(1, N, 3))
+    out = {k: torch.full_like(v, float("nan")) for k, v in with_status.items() if k in ("Esde_t", "Ef", "dEdm", "dEdS", "dth_t", "dSig_t")}
+    _lib.call("vgpa_esde", _lib.SYS_L96_UT, 1, N, D, Ad.data_ptr(), bd.data_ptr(), md.data_ptr(), Sd.data_ptr(),
+              sid.data_ptr(), 0, th.data_ptr(), 0, out["Esde_t"].data_ptr(), out["Ef"].data_ptr(), None,
+              out["dEdm"].data_ptr(), out["dEdS"].data_ptr(), out["dth_t"].data_ptr(), out["dSig_t"].data_ptr(), None,
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        assert torch.equal(v, with_status[k]), k
+    G = with_status["dEdS"]
+    assert torch.equal(G, G.transpose(-1, -2))
+
+
+@pytest.mark.parametrize("method", ["RK2", "RK4"])
+def test_scans_at_the_largest_dimension_with_the_symmetric_flag(method):
+    """D = 60 with RK2 / RK4: the one-product kernels would need six D x (D+1) matrices in
+    LDS, more than a compute unit has; the call must still succeed (general kernels, same
+    bits) and agree with the oracle."""
+    import torch
+    from vgpa_amd import engine
+    rng = np.random.default_rng(60)
+    D, N, dt = 60, 6, 0.01
+    sym = lambda X: 0.5 * (X + np.swapaxes(X, -1, -2))   # noqa: E731
+    A = 4.0 * np.eye(D)[None, None] + 0.3 * rng.standard_normal((1, N, D, D))
+    b = rng.standard_normal((1, N, D))
+    m0 = rng.standard_normal((1, D))
+    S0 = 0.25 * np.eye(D)[None] + 0.02 * sym(rng.standard_normal((1, D, D)))
+    Sig = 2.0 * np.eye(D) + 0.05 * sym(rng.standard_normal((D, D)))
+    gm, gS = rng.standard_normal((1, N, D)), sym(rng.standard_normal((1, N, D, D)))
+    jm, jS = rng.standard_normal((1, N, D)), sym(rng.standard_normal((1, N, D, D)))
+    d = engine.to_dev
+    mid = engine.method_id(method)
+    m1, S1 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=True)
+    m2, S2 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=False)
+    assert torch.equal(S1, S2) and torch.equal(m1, m2)
+    l1, P1 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, dEobs_dS=d(jS), symmetric=True)
+    l2, P2 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, dEobs_dS=d(jS), symmetric=False)
+    assert torch.equal(P1, P2) and torch.equal(l1, l2)
+    mr, Sr = orc.fwd_scan(A[0], b[0], m0[0], S0[0], Sig, dt, method)
+    lr, Pr = orc.bwd_scan(A[0], gm[0], gS[0], jm[0], jS[0], dt, method)
+    assert relerr(S1[0].cpu().numpy(), Sr) <= TOL and relerr(m1[0].cpu().numpy(), mr) <= TOL
+    assert relerr(P1[0].cpu().numpy(), Pr) <= TOL and relerr(l1[0].cpu().numpy(), lr) <= TOL

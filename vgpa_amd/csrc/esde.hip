@@ -512,12 +512,17 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
         for (int j = 0; j < D; ++j) y = fma(Si[l * LD + j], uv[j], y);
         a.dEdm[e * D + l] = 0.5 * w1 * y;
     }
+    // The pivoted inverse is symmetric to rounding only; the lower triangle is computed and
+    // mirrored, so that dEsde/dS is exactly symmetric like the output of the regular steps
+    // (the backward scan's one-product form relies on that).
     double* G = a.dEdS + e * DD;
     for (int i = 0; i < D; ++i) {
-        if (act) {
+        if (act && l <= i) {
             double s = 0.0;
             for (int k = 0; k < D; ++k) s = fma(Si[i * LD + k] * gv[k], Si[k * LD + l], s);
-            G[i * D + l] = 0.25 * w1 * s - 0.5 * Esde * Si[i * LD + l];
+            const double v = 0.25 * w1 * s - 0.5 * Esde * Si[i * LD + l];
+            G[i * D + l] = v;
+            G[(size_t)l * D + i] = v;
         }
     }
 }
@@ -528,8 +533,11 @@ __global__ void __launch_bounds__(64) esde_l96_fixup_kernel(EsdeArgs a, size_t t
     extern __shared__ double lds[];
     const size_t e0 = (size_t)blockIdx.x * 64;
     const size_t mine = e0 + threadIdx.x;
-    const int st = (mine < total) ? a.status[mine] : 0;
-    unsigned long long todo = __ballot((st & VGPA_ST_UNSUPPORTED) != 0);
+    // flagged steps: by the status word, or, when the caller gave no status array, by the NaN
+    // the energy kernel left in Esde_t (a step that is NaN for another reason stays NaN)
+    bool flagged = false;
+    if (mine < total) flagged = a.status ? (a.status[mine] & VGPA_ST_UNSUPPORTED) != 0 : isnan(a.Esde_t[mine]);
+    unsigned long long todo = __ballot(flagged);
     while (todo) {
         const int i = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -761,7 +769,7 @@ void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
     if constexpr (D == 40) launch_l96_wave40(a, st);
     else if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
     else launch_l96_tiled_h<D, false>(a, total, st);
-    if (a.status) {
+    {
         // steps the energy kernel flagged as not positive definite
         const size_t lds = sizeof(double) * ((size_t)3 * D * (D + 1) + 5 * D);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(esde_l96_fixup_kernel),

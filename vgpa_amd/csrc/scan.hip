@@ -869,9 +869,26 @@ size_t nd_lds_bytes(int D, bool fixed, int method, bool sym) {
     return sizeof(double) * (nmat * D * LD + 5 * (size_t)D);
 }
 
+// LDS of one gfx950 compute unit: the most a workgroup can ask for.
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// Whether the n-D kernels can hold their matrices for this size and method at all, and whether
+// the one-product (symmetric) variant, which keeps one more matrix, still fits.
+bool nd_fits(int D, int method, bool sym) {
+    const bool fixed = (D == 40 || D == 16);
+    return nd_lds_bytes(D, fixed, method, sym) <= kLdsLimit;
+}
+
+// Records a refused attribute change: the launch that follows would fail with a generic
+// error, so the reason is kept for vgpa_last_error_string().
+thread_local bool g_lds_refused = false;
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        g_lds_refused = true;
+    }
 }
 
 #include "scan_mfma.h"
@@ -944,7 +961,9 @@ void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const 
 // Expand (method, D, symmetric) into the template instance.
 #define VGPA_DISPATCH_SCAN(LAUNCH, ...)                                              \
     do {                                                                             \
-        const bool sym = (flags & VGPA_SCAN_SYMMETRIC) != 0;                         \
+        /* the symmetric variant keeps one more matrix in LDS: where that does not fit   \
+           (RK2 / RK4 at D >= 58) the general kernel runs instead, with the same bits */   \
+        const bool sym = (flags & VGPA_SCAN_SYMMETRIC) != 0 && nd_fits(D, method, true);  \
         const int dt_ = D == 40 ? 40 : (D == 16 ? 16 : 0);                           \
         VGPA_DISPATCH_M(LAUNCH, VGPA_EULER, dt_, sym, __VA_ARGS__);                  \
         VGPA_DISPATCH_M(LAUNCH, VGPA_HEUN, dt_, sym, __VA_ARGS__);                   \
@@ -969,6 +988,9 @@ extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, c
     VGPA_REQUIRE(A && b && m0 && S0 && Sigma && m_out && S_out, "vgpa_fwd_scan: null pointer argument");
     VGPA_REQUIRE(sigma_stride == 0 || sigma_stride == D * D, "vgpa_fwd_scan: sigma_stride must be 0 or D*D");
     if (P == 0) return VGPA_OK;
+    if (D > 1 && !nd_fits(D, method, false))
+        return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_fwd_scan: D=%d with method %d needs more than the 160 KB of LDS of a compute unit", D, method);
+    g_lds_refused = false;
     hipStream_t st = vgpa::as_stream(stream);
     if (D == 1) {
         const int bs = 64, grid = (P + bs - 1) / bs;
@@ -982,6 +1004,10 @@ extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, c
 #undef LAUNCH1
     } else {
         VGPA_DISPATCH_SCAN(launch_fwd, P, N, D, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out, st);
+    }
+    if (g_lds_refused) {
+        (void)hipGetLastError();
+        return vgpa::fail(VGPA_ELAUNCH, "vgpa_fwd_scan: the LDS size this launch needs was refused (D=%d)", D);
     }
     return vgpa::check_launch("vgpa_fwd_scan");
 }
@@ -997,6 +1023,9 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
     VGPA_REQUIRE(A && dEsde_dm && dEsde_dS && dEobs_dm && lam_out && Psi_out, "vgpa_bwd_scan: null pointer argument");
     VGPA_REQUIRE(jumpS_stride == 0 || jumpS_stride == D * D, "vgpa_bwd_scan: jumpS_stride must be 0 or D*D");
     if (P == 0) return VGPA_OK;
+    if (D > 1 && !nd_fits(D, method, false))
+        return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan: D=%d with method %d needs more than the 160 KB of LDS of a compute unit", D, method);
+    g_lds_refused = false;
     hipStream_t st = vgpa::as_stream(stream);
     if (D == 1) {
         const int bs = 64, grid = (P + bs - 1) / bs;
@@ -1011,6 +1040,10 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
     } else {
         VGPA_DISPATCH_SCAN(launch_bwd, P, N, D, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS,
                            jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out, st);
+    }
+    if (g_lds_refused) {
+        (void)hipGetLastError();
+        return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan: the LDS size this launch needs was refused (D=%d)", D);
     }
     return vgpa::check_launch("vgpa_bwd_scan");
 }

@@ -154,7 +154,10 @@ def make_problem(system, sde, m0, S0, P=1, theta=None, fun=None):
     obs_flag = np.zeros(N, dtype=np.int32)
     obs_flag[obs_idx] = 1
     obsY = np.asarray(sde["obsY"], dtype=np.float64)
-    th = np.asarray(sde["theta"] if theta is None else theta, dtype=np.float64)
+    # a user-supplied energy function (system < 0) owns its drift parameters: the reference's
+    # varFreeEnergy / gradL_Ab never read sde_struct['theta'] themselves
+    th_src = theta if theta is not None else (sde.get("theta", 0.0) if system < 0 else sde["theta"])
+    th = np.asarray(th_src, dtype=np.float64)
     mu0 = np.asarray(sde["px0"]["mu0"], dtype=np.float64)
     tau0 = np.asarray(sde["px0"]["tau0"], dtype=np.float64)
     m0a = np.asarray(m0.cpu() if isinstance(m0, torch.Tensor) else m0, dtype=np.float64)
