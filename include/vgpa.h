@@ -180,6 +180,26 @@ int vgpa_obs_terms(int P, int N, int D, int M, int d,
                    double* Eobs, double* dEobs_dm, double* jumpS, void* stream);
 
 /*
+ * vgpa_obs_terms for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
+ * the reference.  Same arguments and results as vgpa_obs_terms without `work`: the per-
+ * observation energies go to a fixed array inside the library instead (VGPA_OBS_STATIC_MAX
+ * doubles = 1 MiB, held on every GPU the library runs on until the process ends).
+ *   - P * M > VGPA_OBS_STATIC_MAX is refused with VGPA_EINVAL (D > 1; D == 1 needs no scratch).
+ *   - The call allocates and frees nothing.  Its first call on a device looks up the device
+ *     address of the array (hipGetSymbolAddress); make that first call outside a capture.
+ *   - All calls on one GPU share the one array: calls that overlap on the same GPU (two
+ *     streams, two threads) race.  Nothing a previous call left in it is read.
+ */
+#define VGPA_OBS_STATIC_MAX (1 << 17)
+int vgpa_obs_terms_static(int P, int N, int D, int M, int d,
+                          const double* m, const double* S,
+                          const int* obs_idx, const double* obsY, int obsY_stride,
+                          const double* H, const double* Ri, const double* Qi,
+                          double logconst,
+                          double* Eobs, double* dEobs_dm, double* jumpS, void* stream);
+
+/*
  * Initial-state KL energy: replaces core/kl0.py:9 `gauss(m0, S0, lam, Psi,
  * sde_struct)` (energy only; gauss_1D :49, gauss_nD :72).  `m0_is_row` selects
  * the outer-product form the reference produces for a (1,D) mean; 0 gives the

@@ -27,6 +27,7 @@ ST_CHOL_FALLBACK, ST_CHOL_FAILED, ST_UNSUPPORTED = 1, 2, 4
 GRAD_OUTER, GRAD_SIGINV_DIAG = 1, 2
 SCAN_SYMMETRIC = 1
 MAX_D = 60
+OBS_STATIC_MAX = 1 << 17
 
 _c_int, _c_dbl, _ptr = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 
@@ -47,6 +48,8 @@ SIGNATURES = {
     "vgpa_reduce_energy": [_c_int, _c_int, _c_int, _ptr, _ptr, _c_dbl, _ptr, _ptr],
     "vgpa_obs_terms": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
                        _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "vgpa_obs_terms_static": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
+                              _c_dbl, _ptr, _ptr, _ptr, _ptr],
     "vgpa_kl0": [_c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _ptr],
     "vgpa_grad_assemble": [_c_int, _c_int, _c_int] + [_ptr] * 8 + [_c_int, _ptr, _c_int, _ptr, _c_int, _c_dbl, _c_int,
                            _ptr, _ptr, _ptr],

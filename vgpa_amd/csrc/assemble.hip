@@ -1,6 +1,7 @@
 // Time reductions, observation terms, initial-state KL energy and the assembly of
 // dL/dA, dL/db, gfx950.
 #include "common.h"
+#include <mutex>
 #include "linalg.h"
 
 #include <cmath>
@@ -542,20 +543,14 @@ extern "C" int vgpa_reduce_energy(int P, int N, int C, const double* x, const do
     return vgpa::check_launch("vgpa_reduce_energy");
 }
 
-extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m, const double* S,
-                              const int* obs_idx, const double* obsY, int obsY_stride, const double* H,
-                              const double* Ri, const double* Qi, double logconst, double* work, double* Eobs,
-                              double* dEobs_dm, double* jumpS, void* stream) {
-    VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1 && M >= 0, "vgpa_obs_terms: bad sizes P=%d N=%d D=%d M=%d", P, N, D, M);
-    VGPA_REQUIRE(d == D, "vgpa_obs_terms: observation dimension d=%d must equal D=%d", d, D);
-    VGPA_REQUIRE(m && S && (M == 0 || (obs_idx && obsY)) && H && Ri && Eobs && dEobs_dm, "vgpa_obs_terms: null pointer argument");
-    VGPA_REQUIRE(D == 1 || (Qi && work), "vgpa_obs_terms: Qi and work are required for D > 1");
-    VGPA_REQUIRE(obsY_stride == 0 || obsY_stride == M * d, "vgpa_obs_terms: obsY_stride must be 0 or M*d");
-    if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_obs_terms: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
-    if (P == 0) return VGPA_OK;
-    hipStream_t st = vgpa::as_stream(stream);
+namespace {
+
+int obs_terms_impl(const char* who, int P, int N, int D, int M, int d, const double* m, const double* S,
+                   const int* obs_idx, const double* obsY, int obsY_stride, const double* H, const double* Ri,
+                   const double* Qi, double logconst, double* work, double* Eobs, double* dEobs_dm, double* jumpS,
+                   hipStream_t st) {
     hipError_t me = hipMemsetAsync(dEobs_dm, 0, sizeof(double) * (size_t)P * N * D, st);
-    if (me != hipSuccess) return vgpa::fail(VGPA_ELAUNCH, "vgpa_obs_terms: memset: %s", hipGetErrorString(me));
+    if (me != hipSuccess) return vgpa::fail(VGPA_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(me));
     if (D == 1) {
         const int bs = 64, grid = (P + bs - 1) / bs;
         hipLaunchKernelGGL(obs_terms_1d_kernel, dim3(grid), dim3(bs), 0, st, P, N, M, m, S, obs_idx, obsY,
@@ -569,7 +564,83 @@ extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m
             hipLaunchKernelGGL(obs_jump_kernel, dim3(1), dim3(256), sizeof(double) * D * D, st, D, H, Ri, jumpS);
         hipLaunchKernelGGL(obs_finish_kernel, dim3((P + 63) / 64), dim3(64), 0, st, P, M, work, logconst, Eobs);
     }
-    return vgpa::check_launch("vgpa_obs_terms");
+    return vgpa::check_launch(who);
+}
+
+}  // namespace
+
+extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m, const double* S,
+                              const int* obs_idx, const double* obsY, int obsY_stride, const double* H,
+                              const double* Ri, const double* Qi, double logconst, double* work, double* Eobs,
+                              double* dEobs_dm, double* jumpS, void* stream) {
+    VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1 && M >= 0, "vgpa_obs_terms: bad sizes P=%d N=%d D=%d M=%d", P, N, D, M);
+    VGPA_REQUIRE(d == D, "vgpa_obs_terms: observation dimension d=%d must equal D=%d", d, D);
+    VGPA_REQUIRE(m && S && (M == 0 || (obs_idx && obsY)) && H && Ri && Eobs && dEobs_dm, "vgpa_obs_terms: null pointer argument");
+    VGPA_REQUIRE(D == 1 || (Qi && work), "vgpa_obs_terms: Qi and work are required for D > 1");
+    VGPA_REQUIRE(obsY_stride == 0 || obsY_stride == M * d, "vgpa_obs_terms: obsY_stride must be 0 or M*d");
+    if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_obs_terms: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
+    if (P == 0) return VGPA_OK;
+    return obs_terms_impl("vgpa_obs_terms", P, N, D, M, d, m, S, obs_idx, obsY, obsY_stride, H, Ri, Qi, logconst, work,
+                          Eobs, dEobs_dm, jumpS, vgpa::as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------
+// The observation terms for callers that cannot allocate: the per-observation energies
+// (P * M doubles, what vgpa_obs_terms takes as `work`) go to a fixed array of the code object.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) double scratch[VGPA_OBS_STATIC_MAX];
+
+namespace {
+constexpr int kMaxDevices = 64;
+// Device address of `scratch` on each GPU this process has used (every GPU holds its own copy
+// of the array at its own address); resolved once per device, with that device current.
+double* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+int scratch_for_current_device(double** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        (void)hipGetLastError();
+        return vgpa::fail(VGPA_ELAUNCH, "vgpa_obs_terms_static: cannot identify the current device");
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            (void)hipGetLastError();
+            return vgpa::fail(VGPA_ELAUNCH, "vgpa_obs_terms_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        }
+        g_scratch_ptr[dev] = static_cast<double*>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return VGPA_OK;
+}
+}  // namespace
+
+extern "C" int vgpa_obs_terms_static(int P, int N, int D, int M, int d, const double* m, const double* S,
+                                     const int* obs_idx, const double* obsY, int obsY_stride, const double* H,
+                                     const double* Ri, const double* Qi, double logconst, double* Eobs,
+                                     double* dEobs_dm, double* jumpS, void* stream) {
+    VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1 && M >= 0, "vgpa_obs_terms_static: bad sizes P=%d N=%d D=%d M=%d", P, N, D, M);
+    VGPA_REQUIRE(d == D, "vgpa_obs_terms_static: observation dimension d=%d must equal D=%d", d, D);
+    VGPA_REQUIRE(m && S && (M == 0 || (obs_idx && obsY)) && H && Ri && Eobs && dEobs_dm,
+                 "vgpa_obs_terms_static: null pointer argument");
+    VGPA_REQUIRE(D == 1 || Qi, "vgpa_obs_terms_static: Qi is required for D > 1");
+    VGPA_REQUIRE(obsY_stride == 0 || obsY_stride == M * d, "vgpa_obs_terms_static: obsY_stride must be 0 or M*d");
+    if (D > VGPA_MAX_D) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_obs_terms_static: D=%d exceeds VGPA_MAX_D=%d", D, VGPA_MAX_D);
+    if (D > 1 && (size_t)P * (size_t)M > (size_t)VGPA_OBS_STATIC_MAX)
+        return vgpa::fail(VGPA_EINVAL, "vgpa_obs_terms_static: P*M = %zu exceeds the fixed scratch of %d doubles "
+                          "(VGPA_OBS_STATIC_MAX); use vgpa_obs_terms with a caller-provided work array",
+                          (size_t)P * (size_t)M, (int)VGPA_OBS_STATIC_MAX);
+    if (P == 0) return VGPA_OK;
+    double* work = nullptr;
+    const int rc = scratch_for_current_device(&work);
+    if (rc != VGPA_OK) return rc;
+    // every slot obs_finish_kernel reads (p * M + n, n < M) is written by obs_terms_nd_kernel of
+    // this call first, so nothing left by an earlier call is ever read
+    return obs_terms_impl("vgpa_obs_terms_static", P, N, D, M, d, m, S, obs_idx, obsY, obsY_stride, H, Ri, Qi, logconst,
+                          work, Eobs, dEobs_dm, jumpS, vgpa::as_stream(stream));
 }
 
 extern "C" int vgpa_kl0(int P, int D, const double* m0, const double* S0, const double* mu0, int mu0_stride,
