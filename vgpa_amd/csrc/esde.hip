@@ -402,7 +402,8 @@ __device__ inline double wave_sum(double v) {
 // Si = inv(S) that gives
 //   dEsde/dm = (w/2) Si (s .* (v+ - v-))
 //   dEsde/dS = (w/4) Si diag(S_ii (v+ + v-)) Si - (Esde_t/2) Si .
-// One wavefront; Ef / Edf / the theta integrand have been written by the caller.
+// One wavefront.  <f>, <df/dx> and the theta integrand do not depend on the factorisation; they
+// are written here as well, so that a caller may hand over a step it has not touched.
 // LDS: 3 D (D+1) + 5 D doubles.
 // ---------------------------------------------------------------------------
 __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
@@ -459,6 +460,23 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
         double am = 0.0;
         for (int k = 0; k < D; ++k) am = fma(Am[l * LD + k], mv[k], am);
         base = am - bv[l];
+        const double Cxx = Sm[f1 * LD + b1] - Sm[b2 * LD + b1];
+        const double Ef = Cxx + (mv[f1] - mv[b2]) * mv[b1] - m_l + theta;
+        a.Ef[e * D + l] = Ef;
+        if (a.dth_t) a.dth_t[e * D + l] = Ef + base;
+    }
+    if (a.Edf) {
+        double* E = a.Edf + e * DD;
+        for (int q = l; q < (int)DD; q += 64) {
+            const int i = q / D, j = q % D;
+            const int jf1 = (i + 1) % D, jb1 = (i + D - 1) % D, jb2 = (i + 2 * D - 2) % D;
+            double v = 0.0;
+            if (j == i) v = -1.0;
+            if (j == jf1) v = mv[jb1];
+            if (j == jb2) v = -mv[jb1];
+            if (j == jb1) v = mv[jf1] - mv[jb2];
+            E[q] = v;
+        }
     }
     const double kappa = 1.05 * D;
     const double c2 = D + kappa;

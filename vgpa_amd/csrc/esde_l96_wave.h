@@ -135,6 +135,16 @@ struct WvElim {
         }
     }
 };
+__device__ __forceinline__ double wv_rcp1(double p) {
+    double q = __builtin_amdgcn_rcp(p);
+    const double e = fma(-p, q, 1.0);
+    return fma(q, e, q);
+}
+__device__ __forceinline__ double wv_rsqrt1(double p) {
+    double r = __builtin_amdgcn_rsq(p);
+    const double e = fma(-(p * r), r, 1.0);
+    return fma(0.5 * r, e, r);
+}
 template <int K, int NP>
 struct WvPivots {
     static __device__ __forceinline__ void run(double (&x)[NP], int c, double& pivc) {
@@ -142,7 +152,7 @@ struct WvPivots {
             const double piv = wv_row_bcast<K>(x[K]);           // S rows: S[k][k]; M rows: 1
             pivc = (c == K) ? piv : pivc;
             // multipliers -S[k][i] / S[k][k] in lane i of the S rows, copied to the M rows
-            const double ntk = wv_even_rows_to_odd(x[K] * -rcp_refined(piv));
+            const double ntk = wv_even_rows_to_odd(x[K] * -wv_rcp1(piv));
             WvElim<K, K + 1, NP>::run(x, ntk);
             WvPivots<K + 1, NP>::run(x, c, pivc);
         }
@@ -189,8 +199,10 @@ __device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, const 
         for (int i = 0; i < NP; ++i) x[i] = __hiloint2double((i == cm) ? 0x3ff00000 : __double2hiint(x[i]), __double2loint(x[i]));
     }
     double pivc = 1.0;             // pivot of row c (S rows; 1 in the M rows and the padding)
+    __builtin_amdgcn_s_setprio(2);     // the pivot chain is latency-bound and leaves most issue slots to the other wavefronts
     WvPivots<0, NP>::run(x, c, pivc);
-    const double rsc = wv_even_rows_to_odd(rsqrt_refined(pivc));
+    __builtin_amdgcn_s_setprio(0);
+    const double rsc = wv_even_rows_to_odd(wv_rsqrt1(pivc));
     WvScale<0, NP>::run(x, rsc);
     // S lane c: L[c][k] = x[k] for k <= c, to buf[c0 + c][c0 + k]
     // M lane c: T[i][c] = x[i] for i >= c, to buf[c0 + c][c0 + i + 2]
@@ -434,6 +446,11 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 
     WV_STAMP(18);
     WV_RELANE();
+    double a0 = 0.0;          // squared centre-point residual of component `lane`
+    // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
+    // sigma-point pair 16 j + c16, summed over this lane's state indices
+    double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
+    double mb[3][4] = {};
     // ---- phase 3: <f>, A m - b, optionally the dense <df/dx> ------------------------------
     {
         double mk[10];
@@ -452,7 +469,6 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         }
     }
     wave_lds_fence();
-    double a0 = 0.0;          // squared centre-point residual of component `lane`
     {
         const int l = lv;
         int f1, b1, b2;
@@ -508,8 +524,6 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     // ---- phase 4: G = A L, then the sigma-point residuals ---------------------------------
     // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
     // sigma-point pair 16 j + c16, summed over this lane's state indices
-    double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
-    double mb[3][4] = {};
     {
         // the B operands L'[4 s + g4][16 j + c16], s >= 4 j (L' is lower triangular: in the
         // diagonal blocks the entries above the diagonal are read as zero)
@@ -783,7 +797,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
                 if (i < nt) ym[i] = wv_mfma(wa[i], ub, ym[i]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    if (i < nt && j < nt) acc[i][j] = wv_mfma(ao[i], bo[j], acc[i][j]);
+                    if (i < nt && j <= i) acc[i][j] = wv_mfma(ao[i], bo[j], acc[i][j]);
             }
         }
         // (W' u)[16 i + 4 g4 + q] sits in register q of the lanes with c16 == 0
@@ -798,16 +812,25 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         if (lane < D) a.dEdm[e * D + lane] = 0.5 * w1 * c2 * basev[lane];      // (w c / 2) W' u, W = sqrt(c2) W'
     WV_STAMP(25);
         double* Gd = a.dEdS + e * DD;
+            // The result is bitwise symmetric, so only the tiles on and below the diagonal are formed.
+            // A lane holds rows 4 g4 .. 4 g4 + 3 of one column of a tile: stored transposed, that is
+            // four consecutive doubles of row (16 j + c16) -- two 16-byte stores; tiles below the
+            // diagonal are stored both ways.
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if ((i < 2 || g4 < 2) && (j < 2 || c16 < 8)) {
-                    double* dst = Gd + (16 * i + 4 * g4) * D + 16 * j + c16;
+                for (int j = 0; j <= i; ++j) {
+                    if ((i < 2 || g4 < 2) && (j < 2 || c16 < 8)) {
+                        double* dt_ = Gd + (16 * j + c16) * D + 16 * i + 4 * g4;
+                        *reinterpret_cast<double2*>(dt_) = make_double2(acc[i][j][0], acc[i][j][1]);
+                        *reinterpret_cast<double2*>(dt_ + 2) = make_double2(acc[i][j][2], acc[i][j][3]);
+                        if (j < i) {
+                            double* dst = Gd + (16 * i + 4 * g4) * D + 16 * j + c16;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dst[q * D] = acc[i][j][q];
+                            for (int q = 0; q < 4; ++q) dst[q * D] = acc[i][j][q];
+                        }
+                    }
                 }
-            }
     }
     WV_STAMP(26);
 #undef WV_RELANE
