@@ -5,8 +5,8 @@ Workload (BASELINE.json metric): Lorenz-96, D = 40, T = 10, dt = 0.005 (N = 2002
 time points), unscented-transform expectations, Euler integrators; a batch of P
 independent problems (parameter-grid points), synthetic inputs resident in HBM.
 One "step" = varFreeEnergy + gradL_Ab for the whole batch: forward scan,
-observation terms, per-step energy kernel, time reductions, backward scan,
-gradient assembly.  value = P_total * N * steps / time.
+observation terms, per-step energy kernel, time reductions, backward scan fused
+with the gradient assembly.  value = P_total * N * steps / time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode problems|windows]
                   [--problems P] [--micro M] [--no-cpu]
@@ -176,7 +176,7 @@ def main():
     from vgpa_amd import batch, engine, _lib
     comm = batch.DistComm() if world > 1 else batch.SingleComm()
 
-    events = {k: [] for k in ("fwd_scan", "esde", "bwd_scan", "grad_assemble")}
+    events = {k: [] for k in ("fwd_scan", "esde", "bwd_scan_grad")}
 
     def timed_call(name, timed, fn):
         """Run fn between two HIP events recorded on the stream the kernels are launched on
@@ -205,12 +205,11 @@ def main():
             en = timed_call("esde", timed, lambda: engine.esde(
                 prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
             Esde = engine.reduce_energy(en["Esde_t"], prob.w, prob.dt)
-            lam, Psi = timed_call("bwd_scan", timed, lambda: engine.bwd_scan(
-                prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-                obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym_bwd))
+            # backward scan and gradient assembly: one kernel for this configuration
+            lam, Psi, gLA, gLb = timed_call("bwd_scan_grad", timed, lambda: engine.bwd_scan_grad(
+                prob, A, b, m, S, en["dEdm"], en["dEdS"], dEobs_dm, en["Ef"], en["Edf"], jumpS=jumpS,
+                symmetric=sym_bwd, state_symmetric=prob.sym_fwd))
             F = engine.kl0(prob) + Eobs + Esde
-            gLA, gLb = timed_call("grad_assemble", timed, lambda: engine.grad_assemble(
-                prob, A, b, m, S, lam, Psi, en["Ef"], en["Edf"]))
             return F, (gLA, gLb, en["status"])
 
         def step(timed):
@@ -287,11 +286,11 @@ def main():
             esde_ms = kernel_ms["esde"]
             bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
             achieved = units_per_launch * bytes_per_unit / (esde_ms * 1e-3) / 1e9
-            # Algorithmic bytes per (problem, time step) of the other three kernels: forward scan reads
-            # A, b and writes m, S; backward scan reads A, dEsde_dS, dEsde_dm, jumps and writes lam, Psi;
-            # gradient assembly reads A, S, Psi and the vectors and writes dL/dA, dL/db.
+            # Algorithmic bytes per (problem, time step) of the other kernels: forward scan reads A, b
+            # and writes m, S; the fused backward scan + gradient kernel reads A, dEsde_dS, S and five
+            # vectors (dEsde_dm, jumps, m, <f>, b) and writes Psi, dL/dA, lam, dL/db.
             per_unit = {"fwd_scan": 8 * (2 * D * D + 2 * D), "esde": bytes_per_unit,
-                        "bwd_scan": 8 * (3 * D * D + 3 * D), "grad_assemble": 8 * (4 * D * D + 6 * D)}
+                        "bwd_scan_grad": 8 * (5 * D * D + 7 * D)}
             kernels = {k: {"avg_ms": kernel_ms[k], "bytes_per_unit": per_unit[k],
                            "achieved_GBps": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9,
                            "frac": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}

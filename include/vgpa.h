@@ -70,6 +70,10 @@ extern "C" {
                                     one matrix product per stage instead of two; the
                                     result is bit-for-bit that of the general path. */
 
+#define VGPA_SCAN_STATE_SYMMETRIC 2  /* vgpa_bwd_scan_grad only: every S[t] is bitwise symmetric too
+                                       (it is when it came from vgpa_fwd_scan with
+                                       VGPA_SCAN_SYMMETRIC)                                     */
+
 /* largest state dimension the n-D kernels accept */
 #define VGPA_MAX_D 60
 
@@ -110,6 +114,30 @@ int vgpa_bwd_scan(int method, int P, int N, int D,
                   const int* obs_flag, const double* jumpS, int jumpS_stride,
                   double dt, int flags, const double* lam_last, const double* Psi_last,
                   double* lam_out, double* Psi_out, void* stream);
+
+/*
+ * Backward scan and gradient assembly in one call: replaces core/bwd_ode.py:50 `solver(...)`
+ * followed by core/gradL_Ab.py:112 `gradL_Ab_nD` (the loop :156-173 and the scaling :176-177),
+ * i.e. vgpa_bwd_scan followed by vgpa_grad_assemble, with the arguments of both (scan_flags:
+ * VGPA_SCAN_*; grad_flags: VGPA_GRAD_*).  For the Euler method at D = 40 with
+ * VGPA_SCAN_SYMMETRIC | VGPA_SCAN_STATE_SYMMETRIC, flagged jumps (dEobs_dS == NULL), Edf ==
+ * NULL with edf_system == VGPA_SYS_L96_UT and a diagonal SigInv without VGPA_GRAD_OUTER, one
+ * kernel forms the gradient of a row while the scan has that row's A(t), Psi(t), lam(t) in
+ * LDS, so that neither is read from memory a second time; every other configuration runs the
+ * two kernels one after the other.
+ *   -> lam_out (P,N,D), Psi_out (P,N,D,D), gLA (P,N,D,D), gLb (P,N,D).
+ */
+int vgpa_bwd_scan_grad(int method, int P, int N, int D,
+                       const double* A, const double* b, const double* m, const double* S,
+                       const double* dEsde_dm, const double* dEsde_dS,
+                       const double* dEobs_dm, const double* dEobs_dS,
+                       const int* obs_flag, const double* jumpS, int jumpS_stride,
+                       const double* Ef, const double* Edf,
+                       int edf_system, const double* theta, int theta_stride,
+                       const double* SigInv, int sig_stride,
+                       double dt, int scan_flags, int grad_flags,
+                       const double* lam_last, const double* Psi_last,
+                       double* lam_out, double* Psi_out, double* gLA, double* gLb, void* stream);
 
 /*
  * Per-time-step expected SDE energy and its gradients: replaces the loop body of

@@ -1,0 +1,136 @@
+"""The backward scan fused with the gradient assembly (vgpa_bwd_scan_grad) against the two
+separate kernels, the oracle and the golden vectors recorded from the reference
+(core/bwd_ode.py:117-127 + core/gradL_Ab.py:156-177)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr, sde_from_golden, initial_moments
+from oracle import vgpa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def _sym(X):
+    return 0.5 * (X + np.swapaxes(X, -1, -2))
+
+
+def _l96_problem(N, P, seed, dt=0.005):
+    """A Lorenz-96 D = 40 problem with observations at a few rows and random variational
+    parameters; returns (prob, A, b) on the device."""
+    from vgpa_amd import engine, _lib
+    rng = np.random.default_rng(seed)
+    D = 40
+    A = 8.0 * np.eye(D)[None, None] + 0.2 * rng.standard_normal((P, N, D, D))
+    b = 5.0 * rng.standard_normal((P, N, D))
+    obsX = np.unique(rng.integers(0, N, size=max(1, N // 3)))
+    mu0 = rng.standard_normal(D)
+    sde = dict(Sig=np.diag(3.0 + rng.random(D)), theta=8.0, Rig=np.eye(D), D=D, N=N, H=np.eye(D), obsX=obsX,
+               obsY=3.0 * rng.standard_normal((obsX.size, D)), px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)), dt=dt,
+               ode_method="EULER")
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, mu0 + 0.1, 0.25 * np.eye(D), P=P,
+                               theta=np.linspace(7.0, 9.0, P).reshape(P, 1))
+    return prob, engine.to_dev(A), engine.to_dev(b)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 64])
+def test_fused_evaluation_equals_scan_then_assembly(N):
+    import torch
+    from vgpa_amd import engine
+    prob, A, b = _l96_problem(N, 3, 100 + N)
+    assert prob.sym_fwd and prob.sym_jump
+    st = engine.free_energy(prob, A, b, want_edf=False)
+    gLA, gLb = engine.gradient(prob, A, b, st)
+    st2, fA, fb = engine.free_energy_and_gradient(prob, A, b)
+    assert int(st.status.max().item()) == 0
+    # the recurrence is the same arithmetic in both kernels
+    assert torch.equal(st2.Psi, st.Psi) and torch.equal(st2.lam, st.lam) and torch.equal(st2.F, st.F)
+    assert torch.equal(fb, gLb)
+    # the D^3 product runs on the matrix cores in the fused kernel: another summation order
+    assert relerr(fA.cpu().numpy(), gLA.cpu().numpy()) <= 1e-12
+
+
+def test_fused_evaluation_vs_golden_and_oracle():
+    from vgpa_amd import engine, _lib
+    g = load_golden("sys_l96_ut_d40.npz")
+    sde = sde_from_golden(g, "EULER")
+    m0, S0 = initial_moments(g)
+    N, D = int(g["N"]), 40
+    An, bn = orc.unpack_Ab(g["Ab"], N, D)
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=1)
+    st, gLA, gLb = engine.free_energy_and_gradient(prob, engine.to_dev(An[None]), engine.to_dev(bn[None]))
+    got = np.concatenate((gLA.reshape(-1).cpu().numpy(), gLb.reshape(-1).cpu().numpy()))
+    assert relerr(got, g["EULER.grad"].reshape(-1)) <= TOL
+    assert abs(float(st.F[0].item()) - float(g["EULER.F"])) <= TOL * abs(float(g["EULER.F"]))
+    assert relerr(st.Psi[0].cpu().numpy(), g["EULER.Psi"]) <= TOL and relerr(st.lam[0].cpu().numpy(), g["EULER.lam"]) <= TOL
+
+
+@pytest.mark.parametrize("N", [1, 2, 5, 33])
+def test_fused_kernel_with_terminal_state_and_flagged_jumps_vs_oracle(N):
+    """The entry point itself on random symmetric inputs, with a terminal state (time windows
+    hand one in) and jumps at flagged rows; oracle: bwd_scan + grad_L_Ab."""
+    import torch
+    from vgpa_amd import engine, _lib
+    rng = np.random.default_rng(500 + N)
+    D, dt, P = 40, 0.01, 2
+    prob, _, _ = _l96_problem(max(N, 2), P, 7)
+    prob.N = N
+    A = 4.0 * np.eye(D)[None, None] + 0.5 * rng.standard_normal((P, N, D, D))
+    b, m, Ef = (rng.standard_normal((P, N, D)) for _ in range(3))
+    S = 0.3 * np.eye(D)[None, None] + 0.1 * _sym(rng.standard_normal((P, N, D, D)))
+    gm, gS = rng.standard_normal((P, N, D)), _sym(rng.standard_normal((P, N, D, D)))
+    jm = rng.standard_normal((P, N, D))
+    flag = (rng.random(N) < 0.5).astype(np.int32)
+    jump = _sym(rng.standard_normal((D, D)))
+    lamT, PsiT = rng.standard_normal((P, D)), _sym(rng.standard_normal((P, D, D)))
+    d = engine.to_dev
+    prob.dt = dt
+    prob.obs_flag = torch.from_numpy(flag).to(prob.m0.device)
+    lam, Psi, gLA, gLb = engine.bwd_scan_grad(prob, d(A), d(b), d(m), d(S), d(gm), d(gS), d(jm), d(Ef), None,
+                                              jumpS=d(jump), symmetric=True, state_symmetric=True,
+                                              lam_last=d(lamT), Psi_last=d(PsiT))
+    assert torch.equal(Psi, Psi.transpose(-1, -2))
+    Sig = np.linalg.inv(prob.SigInv.cpu().numpy())
+    jS = flag[:, None, None] * jump[None]
+    for p in range(P):
+        lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS, dt, "EULER", lam_last=lamT[p], Psi_last=PsiT[p])
+        assert relerr(Psi[p].cpu().numpy(), Pr) <= TOL and relerr(lam[p].cpu().numpy(), lr) <= TOL
+        _, Edf = orc.l96_ef_edf(m[p], S[p], 8.0)
+        gr = orc.grad_L_Ab(A[p], b[p], m[p], S[p], lr, Pr, Ef[p], Edf, Sig, dt).reshape(-1)
+        got = np.concatenate((gLA[p].reshape(-1).cpu().numpy(), gLb[p].reshape(-1).cpu().numpy()))
+        assert relerr(got, gr) <= TOL
+
+
+@pytest.mark.parametrize("system,fname,method", [("l96_ut", "sys_l96_ut_d6.npz", "HEUN"), ("l63", "sys_l63.npz", "EULER"),
+                                                 ("ou", "sys_ou.npz", "RK4"), ("l96_ut", "sys_l96_ut_d40.npz", "RK2")])
+def test_entry_point_runs_the_two_kernels_for_every_other_configuration(system, fname, method):
+    import torch
+    from vgpa_amd import engine, _lib
+    g = load_golden(fname)
+    sde = sde_from_golden(g, method)
+    m0, S0 = initial_moments(g)
+    N, D = int(g["N"]), int(g["D"])
+    An, bn = orc.unpack_Ab(g["Ab"], N, D)
+    A = engine.to_dev(An.reshape((1, N) if D == 1 else (1, N, D, D)))
+    b = engine.to_dev(bn.reshape((1, N) if D == 1 else (1, N, D)))
+    prob = engine.make_problem(_lib.SYSTEMS[system], sde, m0, S0, P=1)
+    st, gLA, gLb = engine.free_energy_and_gradient(prob, A, b)
+    got = np.concatenate((gLA.reshape(-1).cpu().numpy(), gLb.reshape(-1).cpu().numpy()))
+    assert relerr(got, g[f"{method}.grad"].reshape(-1)) <= TOL
+    st1 = engine.free_energy(prob, A, b, want_edf=(D == 1))
+    g1 = engine.gradient(prob, A, b, st1)
+    assert torch.equal(g1[0], gLA) and torch.equal(g1[1], gLb) and torch.equal(st1.Psi, st.Psi)
+
+
+def test_fused_evaluation_at_the_benchmark_size():
+    """N = 2002 rows, four problems: the fused kernel against the two separate ones."""
+    import torch
+    from vgpa_amd import engine
+    prob, A, b = _l96_problem(2002, 4, 9)
+    st = engine.free_energy(prob, A, b, want_edf=False)
+    gLA, gLb = engine.gradient(prob, A, b, st)
+    st2, fA, fb = engine.free_energy_and_gradient(prob, A, b)
+    assert int(st.status.max().item()) == 0
+    assert torch.equal(st2.Psi, st.Psi) and torch.equal(st2.lam, st.lam) and torch.equal(fb, gLb)
+    assert relerr(fA.cpu().numpy(), gLA.cpu().numpy()) <= 1e-12

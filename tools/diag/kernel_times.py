@@ -38,4 +38,7 @@ print(f"esde       min {t:8.3f} ms  avg {ta:8.3f}  {units * 39688 / t / 1e6:8.1f
 print(f"bwd_scan   min {t:8.3f} ms  avg {ta:8.3f}  {units * 39360 / t / 1e6:8.1f} GB/s")
 (gLA, gLb), t, ta = timed(lambda: engine.grad_assemble(prob, A, b, m, S, lam, Psi, en["Ef"], None))
 print(f"grad       min {t:8.3f} ms  avg {ta:8.3f}  {units * 53120 / t / 1e6:8.1f} GB/s")
-print("checksum", float(en["Esde_t"].sum()), float(gLA.sum()), float(lam.sum()))
+(l2, P2, fA, fb), t, ta = timed(lambda: engine.bwd_scan_grad(prob, A, b, m, S, en["dEdm"], en["dEdS"], dEobs_dm, en["Ef"], None,
+                                                           jumpS=jumpS, symmetric=True, state_symmetric=True))
+print(f"bwd+grad   min {t:8.3f} ms  avg {ta:8.3f}  {units * 66240 / t / 1e6:8.1f} GB/s  (fused)")
+print("checksum", float(en["Esde_t"].sum()), float(gLA.sum()), float(lam.sum()), float((fA - gLA).abs().max()))

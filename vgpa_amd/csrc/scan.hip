@@ -892,6 +892,7 @@ void allow_lds(K kernel, size_t bytes) {
 }
 
 #include "scan_mfma.h"
+#include "scan_fused.h"
 #define VGPA_SMALL_D_SCANS
 #include "small_d.h"
 
@@ -1046,6 +1047,43 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
         return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan: the LDS size this launch needs was refused (D=%d)", D);
     }
     return vgpa::check_launch("vgpa_bwd_scan");
+}
+
+extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double* A, const double* b, const double* m,
+                                  const double* S, const double* dEsde_dm, const double* dEsde_dS,
+                                  const double* dEobs_dm, const double* dEobs_dS, const int* obs_flag,
+                                  const double* jumpS, int jumpS_stride, const double* Ef, const double* Edf,
+                                  int edf_system, const double* theta, int theta_stride, const double* SigInv,
+                                  int sig_stride, double dt, int scan_flags, int grad_flags, const double* lam_last,
+                                  const double* Psi_last, double* lam_out, double* Psi_out, double* gLA, double* gLb,
+                                  void* stream) {
+    VGPA_REQUIRE(method >= VGPA_EULER && method <= VGPA_RK4, "vgpa_bwd_scan_grad: Unknown method of integration (%d)", method);
+    VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_bwd_scan_grad: bad sizes P=%d N=%d D=%d", P, N, D);
+    VGPA_REQUIRE(A && b && m && S && dEsde_dm && dEsde_dS && dEobs_dm && Ef && SigInv && lam_out && Psi_out && gLA && gLb,
+                 "vgpa_bwd_scan_grad: null pointer argument");
+    const bool fused = method == VGPA_EULER && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
+                       (scan_flags & VGPA_SCAN_STATE_SYMMETRIC) && !dEobs_dS && !Edf && edf_system == VGPA_SYS_L96_UT &&
+                       (grad_flags & VGPA_GRAD_SIGINV_DIAG) && !(grad_flags & VGPA_GRAD_OUTER);
+    if (!fused) {
+        // every other configuration: the scan, then the assembly kernel
+        const int rc = vgpa_bwd_scan(method, P, N, D, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS,
+                                     jumpS_stride, dt, scan_flags & VGPA_SCAN_SYMMETRIC, lam_last, Psi_last, lam_out,
+                                     Psi_out, stream);
+        if (rc != VGPA_OK) return rc;
+        return vgpa_grad_assemble(P, N, D, A, b, m, S, lam_out, Psi_out, Ef, Edf, edf_system, theta, theta_stride, SigInv,
+                                  sig_stride, dt, grad_flags, gLA, gLb, stream);
+    }
+    VGPA_REQUIRE(jumpS_stride == 0 || jumpS_stride == D * D, "vgpa_bwd_scan_grad: jumpS_stride must be 0 or D*D");
+    VGPA_REQUIRE(sig_stride == 0 || sig_stride == D * D, "vgpa_bwd_scan_grad: sig_stride must be 0 or D*D");
+    if (P == 0) return VGPA_OK;
+    g_lds_refused = false;
+    const size_t lds = sizeof(double) * M40F::LDS_DOUBLES;
+    allow_lds(bwd_grad_euler_sym_mfma40_kernel, lds);
+    if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan_grad: the LDS size this launch needs was refused");
+    hipLaunchKernelGGL(bwd_grad_euler_sym_mfma40_kernel, dim3(P), dim3(M40F::NT), lds, vgpa::as_stream(stream), N, A, b, m,
+                       S, dEsde_dm, dEsde_dS, dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt,
+                       lam_last, Psi_last, lam_out, Psi_out, gLA, gLb);
+    return vgpa::check_launch("vgpa_bwd_scan_grad");
 }
 
 #ifdef VGPA_STAMPS

@@ -268,6 +268,35 @@ def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, 
     return lam, Psi
 
 
+def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, dEobs_dS=None, symmetric=False,
+                  state_symmetric=False, outer=False, lam_last=None, Psi_last=None, out=None):
+    """vgpa_bwd_scan_grad -> lam, Psi, gLA, gLb: the backward scan and the gradient assembly
+    in one call.  With the Euler method at D = 40, symmetric inputs (``symmetric``: dEdS and
+    the jumps; ``state_symmetric``: S), an implicit Lorenz-96 <df/dx> (Edf None) and a diagonal
+    SigInv one kernel does both; otherwise the library runs the two kernels in sequence."""
+    P, N, D = prob.P, prob.N, prob.D
+    lam = torch.empty_like(dEdm)
+    Psi = torch.empty_like(dEdS)
+    if out is None:
+        gLA, gLb = torch.empty_like(A), torch.empty_like(b)
+    else:
+        gLA, gLb = out
+        if gLA.shape != A.shape or gLb.shape != b.shape or gLA.dtype != F64 or gLb.dtype != F64:
+            raise ValueError("bwd_scan_grad: out tensors must match A and b (float64)")
+    jstride = 0
+    if jumpS is not None and jumpS.numel() == P * D * D and P > 1:
+        jstride = D * D
+    sflags = (_lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0) | \
+             (_lib.SCAN_STATE_SYMMETRIC if (state_symmetric and D > 1) else 0)
+    gflags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
+    n_theta = 3 if prob.system in (_lib.SYS_L63, _lib.SYS_L63_UT) else 1
+    call("vgpa_bwd_scan_grad", prob.method, P, N, D, _p(A), _p(b), _p(m), _p(S), _p(dEdm), _p(dEdS), _p(dEobs_dm),
+         _p(dEobs_dS), _p(prob.obs_flag), _p(jumpS), jstride, _p(Ef), _p(Edf), prob.system, _p(prob.theta),
+         _par_stride(prob.theta, P, n_theta), _p(prob.SigInv), _par_stride(prob.SigInv, P, D * D), float(prob.dt),
+         sflags, gflags, _p(lam_last), _p(Psi_last), _p(lam), _p(Psi), _p(gLA), _p(gLb), _stream())
+    return lam, Psi, gLA, gLb
+
+
 def _par_stride(t, P, per_problem_numel):
     """0 when a parameter tensor is shared, else its per-problem element count."""
     return per_problem_numel if (t.numel() == P * per_problem_numel and P > 1) else 0
@@ -504,6 +533,30 @@ def free_energy(prob, A, b, want_hyper=False, want_edf=True, need_adjoint=True):
 def gradient(prob, A, b, st, outer=False, out=None):
     """core/gradL_Ab.py:156-180 for a batch: (gLA, gLb), already times dt."""
     return grad_assemble(prob, A, b, st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf, outer=outer, out=out)
+
+
+def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer=False, out=None):
+    """core/varFreeEnergy.py:80-111 followed by core/gradL_Ab.py:156-180 for a batch, with the
+    backward scan and the gradient assembly in one library call (one kernel for the Lorenz-96
+    D = 40 Euler case, see ``bwd_scan_grad``).  Returns (State, gLA, gLb)."""
+    if prob.system < 0:
+        st = free_energy(prob, A, b, want_hyper=want_hyper, want_edf=True)
+        gLA, gLb = gradient(prob, A, b, st, outer=outer, out=out)
+        return st, gLA, gLb
+    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
+    Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
+    implicit_ok = prob.D > 1 and prob.system in (_lib.SYS_L96_UT, _lib.SYS_L63, _lib.SYS_L63_UT)
+    en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w, prob.dt,
+                      want_hyper, want_edf=want_edf or not implicit_ok)
+    sym = prob.sym_jump and esde_output_is_symmetric(prob.system, prob.D)
+    lam, Psi, gLA, gLb = bwd_scan_grad(prob, A, b, m, S, en["dEdm"], en["dEdS"], dEobs_dm, en["Ef"], en["Edf"],
+                                       jumpS=jumpS, symmetric=sym, state_symmetric=prob.sym_fwd, outer=outer, out=out)
+    KL0 = kl0(prob)
+    F = KL0 + Eobs + en["Esde"]
+    st = State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"], Edf=en["Edf"],
+               dEdm=en["dEdm"], dEdS=en["dEdS"], dEobs_dm=dEobs_dm, jumpS=jumpS, status=en["status"],
+               dth=en.get("dth"), dSig=en.get("dSig"))
+    return st, gLA, gLb
 
 
 def check_status(status):
