@@ -123,8 +123,9 @@ int vgpa_bwd_scan(int method, int P, int N, int D,
  * VGPA_SCAN_SYMMETRIC | VGPA_SCAN_STATE_SYMMETRIC, flagged jumps (dEobs_dS == NULL), Edf ==
  * NULL with edf_system == VGPA_SYS_L96_UT and a diagonal SigInv without VGPA_GRAD_OUTER, one
  * kernel forms the gradient of a row while the scan has that row's A(t), Psi(t), lam(t) in
- * LDS, so that neither is read from memory a second time; every other configuration runs the
- * two kernels one after the other.
+ * LDS, so that neither is read from memory a second time (used from 161 problems on, where the
+ * call is bound by memory traffic); every other configuration runs the two kernels one after the
+ * other.
  *   -> lam_out (P,N,D), Psi_out (P,N,D,D), gLA (P,N,D,D), gLb (P,N,D).
  */
 int vgpa_bwd_scan_grad(int method, int P, int N, int D,

@@ -16,14 +16,21 @@ def _sym(X):
     return 0.5 * (X + np.swapaxes(X, -1, -2))
 
 
+FUSED_P = 161      # the library fuses from this many problems on
+
+
 def _l96_problem(N, P, seed, dt=0.005):
     """A Lorenz-96 D = 40 problem with observations at a few rows and random variational
     parameters; returns (prob, A, b) on the device."""
+    import torch
     from vgpa_amd import engine, _lib
     rng = np.random.default_rng(seed)
     D = 40
-    A = 8.0 * np.eye(D)[None, None] + 0.2 * rng.standard_normal((P, N, D, D))
-    b = 5.0 * rng.standard_normal((P, N, D))
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    A = 0.2 * torch.randn((P, N, D, D), generator=gen, device=dev, dtype=torch.float64)
+    A += 8.0 * torch.eye(D, device=dev, dtype=torch.float64)
+    b = 5.0 * torch.randn((P, N, D), generator=gen, device=dev, dtype=torch.float64)
     obsX = np.unique(rng.integers(0, N, size=max(1, N // 3)))
     mu0 = rng.standard_normal(D)
     sde = dict(Sig=np.diag(3.0 + rng.random(D)), theta=8.0, Rig=np.eye(D), D=D, N=N, H=np.eye(D), obsX=obsX,
@@ -31,14 +38,14 @@ def _l96_problem(N, P, seed, dt=0.005):
                ode_method="EULER")
     prob = engine.make_problem(_lib.SYS_L96_UT, sde, mu0 + 0.1, 0.25 * np.eye(D), P=P,
                                theta=np.linspace(7.0, 9.0, P).reshape(P, 1))
-    return prob, engine.to_dev(A), engine.to_dev(b)
+    return prob, A, b
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 7, 64])
 def test_fused_evaluation_equals_scan_then_assembly(N):
     import torch
     from vgpa_amd import engine
-    prob, A, b = _l96_problem(N, 3, 100 + N)
+    prob, A, b = _l96_problem(N, FUSED_P, 100 + N)
     assert prob.sym_fwd and prob.sym_jump
     st = engine.free_energy(prob, A, b, want_edf=False)
     gLA, gLb = engine.gradient(prob, A, b, st)
@@ -58,12 +65,15 @@ def test_fused_evaluation_vs_golden_and_oracle():
     m0, S0 = initial_moments(g)
     N, D = int(g["N"]), 40
     An, bn = orc.unpack_Ab(g["Ab"], N, D)
-    prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=1)
-    st, gLA, gLb = engine.free_energy_and_gradient(prob, engine.to_dev(An[None]), engine.to_dev(bn[None]))
-    got = np.concatenate((gLA.reshape(-1).cpu().numpy(), gLb.reshape(-1).cpu().numpy()))
-    assert relerr(got, g["EULER.grad"].reshape(-1)) <= TOL
-    assert abs(float(st.F[0].item()) - float(g["EULER.F"])) <= TOL * abs(float(g["EULER.F"]))
-    assert relerr(st.Psi[0].cpu().numpy(), g["EULER.Psi"]) <= TOL and relerr(st.lam[0].cpu().numpy(), g["EULER.lam"]) <= TOL
+    P = FUSED_P        # copies of the recorded problem: the first and the last are compared
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P)
+    rep = lambda x: engine.to_dev(np.broadcast_to(x, (P,) + x.shape))   # noqa: E731
+    st, gLA, gLb = engine.free_energy_and_gradient(prob, rep(An), rep(bn))
+    for p in (0, P - 1):
+        got = np.concatenate((gLA[p].reshape(-1).cpu().numpy(), gLb[p].reshape(-1).cpu().numpy()))
+        assert relerr(got, g["EULER.grad"].reshape(-1)) <= TOL
+        assert abs(float(st.F[p].item()) - float(g["EULER.F"])) <= TOL * abs(float(g["EULER.F"]))
+        assert relerr(st.Psi[p].cpu().numpy(), g["EULER.Psi"]) <= TOL and relerr(st.lam[p].cpu().numpy(), g["EULER.lam"]) <= TOL
 
 
 @pytest.mark.parametrize("N", [1, 2, 5, 33])
@@ -73,7 +83,7 @@ def test_fused_kernel_with_terminal_state_and_flagged_jumps_vs_oracle(N):
     import torch
     from vgpa_amd import engine, _lib
     rng = np.random.default_rng(500 + N)
-    D, dt, P = 40, 0.01, 2
+    D, dt, P = 40, 0.01, FUSED_P
     prob, _, _ = _l96_problem(max(N, 2), P, 7)
     prob.N = N
     A = 4.0 * np.eye(D)[None, None] + 0.5 * rng.standard_normal((P, N, D, D))
@@ -93,7 +103,7 @@ def test_fused_kernel_with_terminal_state_and_flagged_jumps_vs_oracle(N):
     assert torch.equal(Psi, Psi.transpose(-1, -2))
     Sig = np.linalg.inv(prob.SigInv.cpu().numpy())
     jS = flag[:, None, None] * jump[None]
-    for p in range(P):
+    for p in (0, 1, P - 1):
         lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS, dt, "EULER", lam_last=lamT[p], Psi_last=PsiT[p])
         assert relerr(Psi[p].cpu().numpy(), Pr) <= TOL and relerr(lam[p].cpu().numpy(), lr) <= TOL
         _, Edf = orc.l96_ef_edf(m[p], S[p], 8.0)
@@ -124,10 +134,10 @@ def test_entry_point_runs_the_two_kernels_for_every_other_configuration(system, 
 
 
 def test_fused_evaluation_at_the_benchmark_size():
-    """N = 2002 rows, four problems: the fused kernel against the two separate ones."""
+    """N = 2002 rows: the fused kernel against the two separate ones."""
     import torch
     from vgpa_amd import engine
-    prob, A, b = _l96_problem(2002, 4, 9)
+    prob, A, b = _l96_problem(2002, FUSED_P, 9)
     st = engine.free_energy(prob, A, b, want_edf=False)
     gLA, gLb = engine.gradient(prob, A, b, st)
     st2, fA, fb = engine.free_energy_and_gradient(prob, A, b)

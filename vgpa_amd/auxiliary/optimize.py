@@ -401,7 +401,7 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     is needed only through sum|g| (the 'gradx' column), which is kept as a scalar.
 
     ``evaluate(A, b, need_grad)`` -> (F (P,), grad (P,n) or None) replaces the device
-    evaluation (used by tests); by default it is engine.free_energy + engine.gradient.
+    evaluation (used by tests); by default it is engine.free_energy_and_gradient.
 
     Returns (A, b, F, stat): final parameters, final free energies (P,), and stat with
     'Fx', 'beta', 'gradx' (nit,P) as the per-problem arrays of ``optim_SCG``, 'MaxIt'
@@ -420,8 +420,7 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
         """F at the parameter array v; the gradient goes into g_out."""
         A, b = ops.parts(v)
         if evaluate is None:
-            st = engine.free_energy(prob, A, b, want_edf=prob.D == 1 or prob.system < 0, need_adjoint=True)
-            engine.gradient(prob, A, b, st, out=ops.parts(g_out))
+            st, _, _ = engine.free_energy_and_gradient(prob, A, b, out=ops.parts(g_out))
             return st.F
         F, grad = evaluate(A, b, True)
         gA, gb = ops.rows(g_out)

@@ -373,16 +373,21 @@ class DeviceWindowOps:
         Eobs, dEobs_dm, jumpS = e.obs_terms(p, m, S)
         en = e.energy_terms(p.system, self.A, self.b, m, S, p.SigInv, p.sig_inv_diag, p.theta, p.w, p.dt,
                             want_hyper=self.want_hyper, want_edf=self.want_edf)
-        en.update(Eobs=Eobs, dEobs_dm=dEobs_dm, jumpS=jumpS)
+        en.update(Eobs=Eobs, dEobs_dm=dEobs_dm, jumpS=jumpS, m=m, S=S)
         return en
 
     def bwd(self, en, lam_last, Psi_last):
+        """The backward scan over the local rows; the gradient of those rows is formed in the
+        same library call (one kernel for the Lorenz-96 D = 40 Euler case) and kept for grad()."""
         p, e = self.prob, self._e
         sym = p.sym_jump and e.esde_output_is_symmetric(p.system, p.D)
         if lam_last is not None:
             lam_last, Psi_last = lam_last.contiguous(), Psi_last.contiguous()
-        return e.bwd_scan(p.method, self.A, en["dEdm"], en["dEdS"], en["dEobs_dm"], p.dt, obs_flag=p.obs_flag,
-                          jumpS=en["jumpS"], symmetric=sym, lam_last=lam_last, Psi_last=Psi_last)
+        lam, Psi, gLA, gLb = e.bwd_scan_grad(p, self.A, self.b, en["m"], en["S"], en["dEdm"], en["dEdS"],
+                                             en["dEobs_dm"], en["Ef"], en["Edf"], jumpS=en["jumpS"], symmetric=sym,
+                                             state_symmetric=p.sym_fwd, lam_last=lam_last, Psi_last=Psi_last)
+        en["grad"] = (gLA, gLb)
+        return lam, Psi
 
     def partial_sums(self, en):
         P = self.prob.P
@@ -407,4 +412,4 @@ class DeviceWindowOps:
         return out
 
     def grad(self, en, m, S, lam, Psi):
-        return self._e.grad_assemble(self.prob, self.A, self.b, m, S, lam, Psi, en["Ef"], en["Edf"])
+        return en["grad"]

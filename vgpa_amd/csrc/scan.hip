@@ -1061,7 +1061,11 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_bwd_scan_grad: bad sizes P=%d N=%d D=%d", P, N, D);
     VGPA_REQUIRE(A && b && m && S && dEsde_dm && dEsde_dS && dEobs_dm && Ef && SigInv && lam_out && Psi_out && gLA && gLb,
                  "vgpa_bwd_scan_grad: null pointer argument");
-    const bool fused = method == VGPA_EULER && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
+    // One workgroup per problem: below about 160 problems the chip is not full, a step's latency
+    // and not the memory traffic sets the time, and the separate scan (shorter step) followed by the
+    // fully parallel assembly kernel is faster (measured: 6.5 against 7.9 ms at 128 problems, 9.4
+    // against 8.4 ms at 256, N = 2002).
+    const bool fused = P > 160 && method == VGPA_EULER && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
                        (scan_flags & VGPA_SCAN_STATE_SYMMETRIC) && !dEobs_dS && !Edf && edf_system == VGPA_SYS_L96_UT &&
                        (grad_flags & VGPA_GRAD_SIGINV_DIAG) && !(grad_flags & VGPA_GRAD_OUTER);
     if (!fused) {
