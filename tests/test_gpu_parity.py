@@ -537,3 +537,39 @@ def test_scans_at_the_largest_dimension_with_the_symmetric_flag(method):
     lr, Pr = orc.bwd_scan(A[0], gm[0], gS[0], jm[0], jS[0], dt, method)
     assert relerr(S1[0].cpu().numpy(), Sr) <= TOL and relerr(m1[0].cpu().numpy(), mr) <= TOL
     assert relerr(P1[0].cpu().numpy(), Pr) <= TOL and relerr(l1[0].cpu().numpy(), lr) <= TOL
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("D,N,P", [(3, 2, 1), (3, 8, 17), (3, 10, 16), (3, 26, 40), (2, 7, 5), (2, 33, 20)])
+def test_small_dimension_scans_staged_through_lds_vs_oracle(D, N, P, method):
+    """D = 2, 3 with an even N * D: the scans that move their rows in chunks of eight steps
+    through LDS (sixteen problems per wavefront).  Chunk edges, partial chunks, partial groups of
+    problems, flagged jumps and a terminal state; every problem against the oracle."""
+    import torch
+    from vgpa_amd import engine
+    rng = np.random.default_rng(1000 * D + N + P)
+    dt = 0.01
+    A = 4.0 * np.eye(D)[None, None] + 0.5 * rng.standard_normal((P, N, D, D))
+    b = rng.standard_normal((P, N, D))
+    m0 = rng.standard_normal((P, D))
+    S0 = 0.25 * np.eye(D)[None] + 0.05 * rng.standard_normal((P, D, D))
+    Sig = 2.0 * np.eye(D) + 0.1 * rng.standard_normal((D, D))
+    gm, gS = rng.standard_normal((P, N, D)), rng.standard_normal((P, N, D, D))
+    jm = rng.standard_normal((P, N, D))
+    flag = (rng.random(N) < 0.4).astype(np.int32)
+    jump = rng.standard_normal((D, D))
+    lamT, PsiT = rng.standard_normal((P, D)), rng.standard_normal((P, D, D))
+    d = engine.to_dev
+    mid = engine.method_id(method)
+    m1, S1 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=False)
+    l1, P1 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, obs_flag=torch.from_numpy(flag).to(m1.device),
+                             jumpS=d(jump), lam_last=d(lamT), Psi_last=d(PsiT))
+    jS = flag[:, None, None] * jump[None]
+    for p in range(P):
+        mr, Sr = orc.fwd_scan(A[p], b[p], m0[p], S0[p], Sig, dt, method)
+        assert relerr(S1[p].cpu().numpy(), Sr) <= TOL and relerr(m1[p].cpu().numpy(), mr) <= TOL, p
+        lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS, dt, method, lam_last=lamT[p], Psi_last=PsiT[p])
+        assert relerr(P1[p].cpu().numpy(), Pr) <= TOL and relerr(l1[p].cpu().numpy(), lr) <= TOL, p
+    # a problem gives the same bits alone as inside a batch
+    m2, S2 = engine.fwd_scan(mid, d(A[-1:]), d(b[-1:]), d(m0[-1:]), d(S0[-1:]), d(Sig), dt, symmetric=False)
+    assert torch.equal(S2[0], S1[-1]) and torch.equal(m2[0], m1[-1])

@@ -899,6 +899,16 @@ void allow_lds(K kernel, size_t bytes) {
 template <int METHOD>
 bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                       const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
+    // RK4 evaluates the moment equations four times per step out of registers: its time is the
+    // arithmetic chain of one lane, which the register-ring kernel below keeps shorter.
+    if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && METHOD != VGPA_RK4) {
+        // 16-byte pieces through LDS, sixteen problems per wavefront
+        const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
+#define VGPA_FL(DD_) hipLaunchKernelGGL((fwd_scan_small_lds_kernel<DD_, METHOD>), dim3(gl), dim3(64), 0, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
+        if (D == 2) VGPA_FL(2); else VGPA_FL(3);
+#undef VGPA_FL
+        return true;
+    }
     const unsigned grid = (unsigned)((P + 63) / 64);
 #define VGPA_FS(DD_) hipLaunchKernelGGL((fwd_scan_small_kernel<DD_, METHOD>), dim3(grid), dim3(64), 0, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
     if (D == 2) VGPA_FS(2); else if (D == 3) VGPA_FS(3); else return false;
@@ -910,6 +920,13 @@ template <int METHOD>
 bool launch_bwd_small(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                       const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                       const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
+    if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && !jS) {
+        const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
+#define VGPA_BL(DD_) hipLaunchKernelGGL((bwd_scan_small_lds_kernel<DD_, METHOD>), dim3(gl), dim3(64), 0, st, P, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out)
+        if (D == 2) VGPA_BL(2); else VGPA_BL(3);
+#undef VGPA_BL
+        return true;
+    }
     const unsigned grid = (unsigned)((P + 63) / 64);
 #define VGPA_BS(DD_) hipLaunchKernelGGL((bwd_scan_small_kernel<DD_, METHOD>), dim3(grid), dim3(64), 0, st, P, N, A, dEdm, dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out)
     if (D == 2) VGPA_BS(2); else if (D == 3) VGPA_BS(3); else return false;

@@ -93,6 +93,141 @@ struct SmallD {
 #pragma unroll
         for (int q = 0; q < n; ++q) y[q] = x[q] + c * k[q];
     }
+    // One step of the forward moment equations, row t -> t + 1 (At, bt: row t; An, bn: row t + 1).
+    // core/fwd_ode.py euler_nD :121-131, heun_nD :218-243, rk2_nD :349-363, rk4_nD :460-489.
+    template <int METHOD>
+    static __device__ __forceinline__ void fwd_step(const double (&At)[DD], const double (&bt)[D], const double (&An)[DD],
+                                                    const double (&bn)[D], const double (&Sg)[DD], double dt,
+                                                    double (&S)[DD], double (&m)[D]) {
+        using T = SmallD<D>;
+        const double h = 0.5 * dt;
+        double k1[DD], f1[D], Sn[DD], mn[D];
+        T::fwd_rhs(At, S, Sg, k1);
+        T::fwd_rhs_vec(At, m, bt, f1);
+        if (METHOD == VGPA_EULER) {
+            T::axpy(S, dt, k1, Sn);
+            T::axpy(m, dt, f1, mn);
+        } else if (METHOD == VGPA_HEUN) {
+            double tS[DD], tm[D], k2[DD], f2[D];
+            T::axpy(S, dt, k1, tS);
+            T::axpy(m, dt, f1, tm);
+            T::fwd_rhs(An, tS, Sg, k2);
+            T::fwd_rhs_vec(An, tm, bn, f2);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) Sn[q] = S[q] + h * (k1[q] + k2[q]);
+#pragma unroll
+            for (int q = 0; q < D; ++q) mn[q] = m[q] + h * (f1[q] + f2[q]);
+        } else if (METHOD == VGPA_RK2) {
+            double Ak[DD], bk[D], tS[DD], tm[D], k2[DD], f2[D];
+            T::mid(At, An, Ak);
+            T::mid(bt, bn, bk);
+            T::axpy(S, h, k1, tS);
+            T::axpy(m, h, f1, tm);
+            T::fwd_rhs(Ak, tS, Sg, k2);
+            T::fwd_rhs_vec(Ak, tm, bk, f2);
+            T::axpy(S, dt, k2, Sn);
+            T::axpy(m, dt, f2, mn);
+        } else {
+            double Ak[DD], bk[D], tS[DD], tm[D], L1[DD], L2[DD], L3[DD], L4[DD], K1[D], K2[D], K3[D], K4[D];
+            T::mid(At, An, Ak);
+            T::mid(bt, bn, bk);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L1[q] = k1[q] * dt; tS[q] = S[q] + 0.5 * L1[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K1[q] = f1[q] * dt; tm[q] = m[q] + 0.5 * K1[q]; }
+            T::fwd_rhs(Ak, tS, Sg, L2);
+            T::fwd_rhs_vec(Ak, tm, bk, K2);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L2[q] *= dt; tS[q] = S[q] + 0.5 * L2[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K2[q] *= dt; tm[q] = m[q] + 0.5 * K2[q]; }
+            T::fwd_rhs(Ak, tS, Sg, L3);
+            T::fwd_rhs_vec(Ak, tm, bk, K3);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L3[q] *= dt; tS[q] = S[q] + L3[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K3[q] *= dt; tm[q] = m[q] + K3[q]; }
+            T::fwd_rhs(An, tS, Sg, L4);
+            T::fwd_rhs_vec(An, tm, bn, K4);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L4[q] *= dt; Sn[q] = S[q] + (L1[q] + 2.0 * (L2[q] + L3[q]) + L4[q]) / 6.0; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K4[q] *= dt; mn[q] = m[q] + (K1[q] + 2.0 * (K2[q] + K3[q]) + K4[q]) / 6.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < DD; ++q) S[q] = Sn[q];
+#pragma unroll
+        for (int q = 0; q < D; ++q) m[q] = mn[q];
+    }
+    // One step of the backward equations without the jumps, row t -> t - 1 (At, Gt, gt: row t;
+    // Ap1, Gp, gp: row t - 1).  core/bwd_ode.py euler_nD :117-127, heun_nD :211-237, rk2_nD :338-362,
+    // rk4_nD :458-493.
+    template <int METHOD>
+    static __device__ __forceinline__ void bwd_step(const double (&At)[DD], const double (&Gt)[DD], const double (&gt)[D],
+                                                    const double (&Ap1)[DD], const double (&Gp)[DD], const double (&gp)[D],
+                                                    double dt, double (&X)[DD], double (&x)[D]) {
+        using T = SmallD<D>;
+        const double h = 0.5 * dt;
+        double k1[DD], f1[D], Xn[DD], xn[D];
+        T::bwd_rhs(At, X, Gt, k1);
+        T::bwd_rhs_vec(At, x, gt, f1);
+        if (METHOD == VGPA_EULER) {
+            T::axpy(X, -dt, k1, Xn);
+            T::axpy(x, -dt, f1, xn);
+        } else if (METHOD == VGPA_HEUN) {
+            double tX[DD], tx[D], k2[DD], f2[D];
+            T::axpy(X, -dt, k1, tX);
+            T::axpy(x, -dt, f1, tx);
+            T::bwd_rhs(Ap1, tX, Gp, k2);
+            T::bwd_rhs_vec(Ap1, tx, gp, f2);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) Xn[q] = X[q] - h * (k1[q] + k2[q]);
+#pragma unroll
+            for (int q = 0; q < D; ++q) xn[q] = x[q] - h * (f1[q] + f2[q]);
+        } else if (METHOD == VGPA_RK2) {
+            double Ak[DD], Gk[DD], gk[D], tX[DD], tx[D], k2[DD], f2[D];
+            T::mid(Ap1, At, Ak);
+            T::mid(Gp, Gt, Gk);
+            T::mid(gp, gt, gk);
+            T::axpy(X, -h, k1, tX);
+            T::axpy(x, -h, f1, tx);
+            T::bwd_rhs(Ak, tX, Gk, k2);
+            T::bwd_rhs_vec(Ak, tx, gk, f2);
+            T::axpy(X, -dt, k2, Xn);
+            T::axpy(x, -dt, f2, xn);
+        } else {
+            double Ak[DD], Gk[DD], gk[D], tX[DD], tx[D], L1[DD], L2[DD], L3[DD], L4[DD], K1[D], K2[D], K3[D], K4[D];
+            T::mid(Ap1, At, Ak);
+            T::mid(Gp, Gt, Gk);
+            T::mid(gp, gt, gk);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L1[q] = k1[q] * dt; tX[q] = X[q] - 0.5 * L1[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K1[q] = f1[q] * dt; tx[q] = x[q] - 0.5 * K1[q]; }
+            T::bwd_rhs(Ak, tX, Gk, L2);
+            T::bwd_rhs_vec(Ak, tx, gk, K2);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L2[q] *= dt; tX[q] = X[q] - 0.5 * L2[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K2[q] *= dt; tx[q] = x[q] - 0.5 * K2[q]; }
+            T::bwd_rhs(Ak, tX, Gk, L3);
+            T::bwd_rhs_vec(Ak, tx, gk, K3);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L3[q] *= dt; tX[q] = X[q] - L3[q]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K3[q] *= dt; tx[q] = x[q] - K3[q]; }
+            T::bwd_rhs(Ap1, tX, Gp, L4);
+            T::bwd_rhs_vec(Ap1, tx, gp, K4);
+#pragma unroll
+            for (int q = 0; q < DD; ++q) { L4[q] *= dt; Xn[q] = X[q] - (L1[q] + 2.0 * (L2[q] + L3[q]) + L4[q]) / 6.0; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) { K4[q] *= dt; xn[q] = x[q] - (K1[q] + 2.0 * (K2[q] + K3[q]) + K4[q]) / 6.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < DD; ++q) X[q] = Xn[q];
+#pragma unroll
+        for (int q = 0; q < D; ++q) x[q] = xn[q];
+    }
 };
 
 #ifdef VGPA_SMALL_D_SCANS
@@ -137,63 +272,7 @@ fwd_scan_small_kernel(int P, int N, const double* __restrict__ A, const double* 
             const double (&bt)[D] = br[u];
             const double (&An)[DD] = Ar[(u + 1) % RING];
             const double (&bn)[D] = br[(u + 1) % RING];
-            double k1[DD], f1[D], Sn[DD], mn[D];
-            T::fwd_rhs(At, S, Sg, k1);
-            T::fwd_rhs_vec(At, m, bt, f1);
-            if (METHOD == VGPA_EULER) {
-                T::axpy(S, dt, k1, Sn);
-                T::axpy(m, dt, f1, mn);
-            } else if (METHOD == VGPA_HEUN) {
-                double tS[DD], tm[D], k2[DD], f2[D];
-                T::axpy(S, dt, k1, tS);
-                T::axpy(m, dt, f1, tm);
-                T::fwd_rhs(An, tS, Sg, k2);
-                T::fwd_rhs_vec(An, tm, bn, f2);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) Sn[q] = S[q] + h * (k1[q] + k2[q]);
-#pragma unroll
-                for (int q = 0; q < D; ++q) mn[q] = m[q] + h * (f1[q] + f2[q]);
-            } else if (METHOD == VGPA_RK2) {
-                double Ak[DD], bk[D], tS[DD], tm[D], k2[DD], f2[D];
-                T::mid(At, An, Ak);
-                T::mid(bt, bn, bk);
-                T::axpy(S, h, k1, tS);
-                T::axpy(m, h, f1, tm);
-                T::fwd_rhs(Ak, tS, Sg, k2);
-                T::fwd_rhs_vec(Ak, tm, bk, f2);
-                T::axpy(S, dt, k2, Sn);
-                T::axpy(m, dt, f2, mn);
-            } else {
-                double Ak[DD], bk[D], tS[DD], tm[D], L1[DD], L2[DD], L3[DD], L4[DD], K1[D], K2[D], K3[D], K4[D];
-                T::mid(At, An, Ak);
-                T::mid(bt, bn, bk);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L1[q] = k1[q] * dt; tS[q] = S[q] + 0.5 * L1[q]; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K1[q] = f1[q] * dt; tm[q] = m[q] + 0.5 * K1[q]; }
-                T::fwd_rhs(Ak, tS, Sg, L2);
-                T::fwd_rhs_vec(Ak, tm, bk, K2);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L2[q] *= dt; tS[q] = S[q] + 0.5 * L2[q]; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K2[q] *= dt; tm[q] = m[q] + 0.5 * K2[q]; }
-                T::fwd_rhs(Ak, tS, Sg, L3);
-                T::fwd_rhs_vec(Ak, tm, bk, K3);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L3[q] *= dt; tS[q] = S[q] + L3[q]; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K3[q] *= dt; tm[q] = m[q] + K3[q]; }
-                T::fwd_rhs(An, tS, Sg, L4);
-                T::fwd_rhs_vec(An, tm, bn, K4);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L4[q] *= dt; Sn[q] = S[q] + (L1[q] + 2.0 * (L2[q] + L3[q]) + L4[q]) / 6.0; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K4[q] *= dt; mn[q] = m[q] + (K1[q] + 2.0 * (K2[q] + K3[q]) + K4[q]) / 6.0; }
-            }
-#pragma unroll
-            for (int q = 0; q < DD; ++q) S[q] = Sn[q];
-#pragma unroll
-            for (int q = 0; q < D; ++q) m[q] = mn[q];
+            T::template fwd_step<METHOD>(At, bt, An, bn, Sg, dt, S, m);
             T::store(So + (size_t)(t + 1) * DD, S);
             T::store(mo + (size_t)(t + 1) * D, m);
             // slot u is free: fetch row t + RING (clamped: a redundant load instead of a branch)
@@ -271,65 +350,11 @@ bwd_scan_small_kernel(int P, int N, const double* __restrict__ A, const double* 
 #pragma unroll
                 for (int q = 0; q < DD; ++q) jd[q] = on ? jt[q] : 0.0;
             }
-            double k1[DD], f1[D], Xn[DD], xn[D];
-            T::bwd_rhs(At, X, Gt, k1);
-            T::bwd_rhs_vec(At, x, gt, f1);
-            if (METHOD == VGPA_EULER) {
-                T::axpy(X, -dt, k1, Xn);
-                T::axpy(x, -dt, f1, xn);
-            } else if (METHOD == VGPA_HEUN) {
-                double tX[DD], tx[D], k2[DD], f2[D];
-                T::axpy(X, -dt, k1, tX);
-                T::axpy(x, -dt, f1, tx);
-                T::bwd_rhs(Ap1, tX, Gp, k2);
-                T::bwd_rhs_vec(Ap1, tx, gp, f2);
+            T::template bwd_step<METHOD>(At, Gt, gt, Ap1, Gp, gp, dt, X, x);
 #pragma unroll
-                for (int q = 0; q < DD; ++q) Xn[q] = X[q] - h * (k1[q] + k2[q]);
+            for (int q = 0; q < DD; ++q) X[q] += jd[q];
 #pragma unroll
-                for (int q = 0; q < D; ++q) xn[q] = x[q] - h * (f1[q] + f2[q]);
-            } else if (METHOD == VGPA_RK2) {
-                double Ak[DD], Gk[DD], gk[D], tX[DD], tx[D], k2[DD], f2[D];
-                T::mid(Ap1, At, Ak);
-                T::mid(Gp, Gt, Gk);
-                T::mid(gp, gt, gk);
-                T::axpy(X, -h, k1, tX);
-                T::axpy(x, -h, f1, tx);
-                T::bwd_rhs(Ak, tX, Gk, k2);
-                T::bwd_rhs_vec(Ak, tx, gk, f2);
-                T::axpy(X, -dt, k2, Xn);
-                T::axpy(x, -dt, f2, xn);
-            } else {
-                double Ak[DD], Gk[DD], gk[D], tX[DD], tx[D], L1[DD], L2[DD], L3[DD], L4[DD], K1[D], K2[D], K3[D], K4[D];
-                T::mid(Ap1, At, Ak);
-                T::mid(Gp, Gt, Gk);
-                T::mid(gp, gt, gk);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L1[q] = k1[q] * dt; tX[q] = X[q] - 0.5 * L1[q]; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K1[q] = f1[q] * dt; tx[q] = x[q] - 0.5 * K1[q]; }
-                T::bwd_rhs(Ak, tX, Gk, L2);
-                T::bwd_rhs_vec(Ak, tx, gk, K2);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L2[q] *= dt; tX[q] = X[q] - 0.5 * L2[q]; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K2[q] *= dt; tx[q] = x[q] - 0.5 * K2[q]; }
-                T::bwd_rhs(Ak, tX, Gk, L3);
-                T::bwd_rhs_vec(Ak, tx, gk, K3);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L3[q] *= dt; tX[q] = X[q] - L3[q]; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K3[q] *= dt; tx[q] = x[q] - K3[q]; }
-                T::bwd_rhs(Ap1, tX, Gp, L4);
-                T::bwd_rhs_vec(Ap1, tx, gp, K4);
-#pragma unroll
-                for (int q = 0; q < DD; ++q) { L4[q] *= dt; Xn[q] = X[q] - (L1[q] + 2.0 * (L2[q] + L3[q]) + L4[q]) / 6.0; }
-#pragma unroll
-                for (int q = 0; q < D; ++q) { K4[q] *= dt; xn[q] = x[q] - (K1[q] + 2.0 * (K2[q] + K3[q]) + K4[q]) / 6.0; }
-            }
-#pragma unroll
-            for (int q = 0; q < DD; ++q) X[q] = Xn[q] + jd[q];
-#pragma unroll
-            for (int q = 0; q < D; ++q) x[q] = xn[q] + jv[q];
+            for (int q = 0; q < D; ++q) x[q] += jv[q];
             T::store(Po + (size_t)(t - 1) * DD, X);
             T::store(lo + (size_t)(t - 1) * D, x);
             // slot u is free: fetch row t - RING (clamped)
@@ -340,6 +365,281 @@ bwd_scan_small_kernel(int P, int N, const double* __restrict__ A, const double* 
             T::load(jmp + (size_t)r * D, jr[u]);
             fr[u] = flagged ? obs_flag[r] : 0;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same scans with their global traffic staged through LDS.
+//
+// In the kernels above every lane walks the rows of its own problem, so each load or store
+// instruction touches 64 different cache lines and the address path, not the arithmetic, sets
+// the time.  Here one wavefront owns PB = 16 problems and moves their rows in chunks of T = 8
+// time steps: four lanes copy the (contiguous) chunk of each problem with 16-byte accesses,
+// LDS holds the chunk problem by problem with an odd stride, and lane p < PB integrates
+// problem p out of LDS.  The inputs of the next chunk are in flight (in registers) while the
+// current one is integrated; results go back through LDS the same way.  Sixteen problems per
+// wavefront also spread a grid of a few thousand problems over every compute unit.
+//
+// Pieces are 16 bytes, so N * D must be even (N * D * D then is too); other sizes take the
+// kernels above.  Same step arithmetic, same bits.
+// ---------------------------------------------------------------------------
+struct SmallLds {
+    static constexpr int PB = 16, T = 8, R = 10;     // problems per wavefront, steps and staged rows per chunk
+    // Four lanes move the chunk of one problem: lane l belongs to problem l / 4 of the wavefront's sixteen and
+    // moves the 16-byte pieces 4 k + l % 4, k = 0, 1, ... of that problem's chunk.  A lane's global and LDS
+    // addresses are then one base each plus a compile-time offset per instruction; an instruction touches a
+    // 64-byte segment per problem, and consecutive instructions complete the cache lines.
+    static __device__ __forceinline__ int prob_of(int lane) { return lane >> 2; }
+    static __device__ __forceinline__ int sub_of(int lane) { return lane & 3; }
+    // Rows [row0, row0 + R) of a (P, N, RD) array.  `pbase` is the element offset of this lane's problem
+    // (clamped to the last problem), EDGE chunks clamp rows outside [0, N) to the edge rows.
+    template <int RD>
+    struct In {
+        static constexpr int CH = R * RD, CH2 = CH / 2, STRIDE = CH | 1, NI = (CH2 + 3) / 4;
+        static constexpr int LDS = PB * STRIDE;
+        template <bool EDGE>
+        static __device__ __forceinline__ void fetch(const double* __restrict__ src, size_t pbase, long long per,
+                                                     long long row0, int lane, double (&pre)[2 * NI]) {
+            const int sub = sub_of(lane);
+            const double* base = src + pbase + row0 * RD + 2 * sub;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int e2 = (4 * k + 3 < CH2) ? 4 * k + sub : min(4 * k + sub, CH2 - 1);
+                double2 v;
+                if (EDGE) {
+                    long long off = row0 * RD + 2 * e2;
+                    off = off < 0 ? 0 : (off > per - 2 ? per - 2 : off);      // rows outside [0, N) repeat the edge
+                    v = *reinterpret_cast<const double2*>(src + pbase + off);
+                } else {
+                    v = *reinterpret_cast<const double2*>(base + 2 * (e2 - sub));
+                }
+                pre[2 * k] = v.x;
+                pre[2 * k + 1] = v.y;
+            }
+        }
+        static __device__ __forceinline__ void commit(const double (&pre)[2 * NI], int lane, double* dst) {
+            const int sub = sub_of(lane);
+            double* base = dst + prob_of(lane) * STRIDE + 2 * sub;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int e2 = (4 * k + 3 < CH2) ? 4 * k + sub : min(4 * k + sub, CH2 - 1);   // tail lanes repeat a piece
+                base[2 * (e2 - sub)] = pre[2 * k];
+                base[2 * (e2 - sub) + 1] = pre[2 * k + 1];
+            }
+        }
+    };
+    // Rows [row0, row0 + T) of a (P, N, RD) array, LDS -> global.  `valid`: this lane's problem exists;
+    // EDGE chunks skip rows >= N.
+    template <int RD>
+    struct Out {
+        static constexpr int CH = T * RD, CH2 = CH / 2, STRIDE = CH | 1, NI = CH2 / 4;
+        static_assert(CH2 % 4 == 0, "whole groups of four pieces");
+        static constexpr int LDS = PB * STRIDE;
+        template <bool EDGE>
+        static __device__ __forceinline__ void flush(const double* src, double* __restrict__ dst, size_t pbase, long long per,
+                                                     long long row0, bool valid, int lane) {
+            const int sub = sub_of(lane);
+            const double* sb = src + prob_of(lane) * STRIDE + 2 * sub;
+            double* db = dst + pbase + row0 * RD + 2 * sub;
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    if (!EDGE || row0 * RD + 2 * (4 * k + sub) + 1 < per)
+                        *reinterpret_cast<double2*>(db + 8 * k) = make_double2(sb[8 * k], sb[8 * k + 1]);
+                }
+            }
+        }
+    };
+    static __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+};
+
+template <int D, int METHOD>
+__global__ void __launch_bounds__(64, 1)
+fwd_scan_small_lds_kernel(int P, int N, const double* __restrict__ A, const double* __restrict__ b,
+                          const double* __restrict__ m0, const double* __restrict__ S0,
+                          const double* __restrict__ Sigma, int sigma_stride, double dt,
+                          double* __restrict__ m_out, double* __restrict__ S_out) {
+    using Tm = SmallD<D>;
+    using L = SmallLds;
+    constexpr int DD = Tm::DD, PB = L::PB, T = L::T;
+    using InA = L::In<DD>;
+    using Inb = L::In<D>;
+    using OutS = L::Out<DD>;
+    using Outm = L::Out<D>;
+    __shared__ double lds[InA::LDS + Inb::LDS + OutS::LDS + Outm::LDS];
+    double* inA = lds;
+    double* inb = inA + InA::LDS;
+    double* outS = inb + Inb::LDS;
+    double* outm = outS + OutS::LDS;
+    const int lane = threadIdx.x;
+    const int p0 = blockIdx.x * PB;
+    const bool act = lane < PB && p0 + lane < P;
+    const int p = min(p0 + min(lane, PB - 1), P - 1);
+    double Sg[DD], S[DD], m[D];
+    Tm::load(Sigma + (size_t)p * sigma_stride, Sg);
+    Tm::load(S0 + (size_t)p * DD, S);
+    Tm::load(m0 + (size_t)p * D, m);
+    // staging: this lane's problem (four lanes per problem) and its element offsets in the arrays
+    const int sp = min(p0 + L::prob_of(lane), P - 1);
+    const bool svalid = p0 + L::prob_of(lane) < P;
+    const long long perA = (long long)N * DD, perb = (long long)N * D;
+    const size_t baseA = (size_t)sp * perA, baseb = (size_t)sp * perb;
+    double preA[2 * InA::NI], preb[2 * Inb::NI];
+    InA::template fetch<true>(A, baseA, perA, 0, lane, preA);
+    Inb::template fetch<true>(b, baseb, perb, 0, lane, preb);
+    const double* myA = inA + min(lane, PB - 1) * InA::STRIDE;
+    const double* myb = inb + min(lane, PB - 1) * Inb::STRIDE;
+    double* myS = outS + min(lane, PB - 1) * OutS::STRIDE;
+    double* mym = outm + min(lane, PB - 1) * Outm::STRIDE;
+    for (int t0 = 0; t0 < N; t0 += T) {
+        InA::commit(preA, lane, inA);
+        Inb::commit(preb, lane, inb);
+        L::fence();
+        // the next chunk, in flight during this one (edge rows are clamped in the last two chunks only)
+        if (t0 + T + L::R <= N) {
+            InA::template fetch<false>(A, baseA, perA, t0 + T, lane, preA);
+            Inb::template fetch<false>(b, baseb, perb, t0 + T, lane, preb);
+        } else {
+            InA::template fetch<true>(A, baseA, perA, t0 + T, lane, preA);
+            Inb::template fetch<true>(b, baseb, perb, t0 + T, lane, preb);
+        }
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                // row t0 + u is the current state; then one step with rows u, u + 1 of the chunk
+                Tm::store(myS + u * DD, S);
+                Tm::store(mym + u * D, m);
+                double At[DD], An[DD], bt[D], bn[D];
+                Tm::load(myA + u * DD, At);
+                Tm::load(myb + u * D, bt);
+                if (METHOD != VGPA_EULER) {
+                    Tm::load(myA + (u + 1) * DD, An);
+                    Tm::load(myb + (u + 1) * D, bn);
+                }
+                Tm::template fwd_step<METHOD>(At, bt, An, bn, Sg, dt, S, m);
+            }
+        }
+        L::fence();
+        if (t0 + T <= N) {
+            OutS::template flush<false>(outS, S_out, baseA, perA, t0, svalid, lane);
+            Outm::template flush<false>(outm, m_out, baseb, perb, t0, svalid, lane);
+        } else {
+            OutS::template flush<true>(outS, S_out, baseA, perA, t0, svalid, lane);
+            Outm::template flush<true>(outm, m_out, baseb, perb, t0, svalid, lane);
+        }
+        L::fence();
+    }
+}
+
+template <int D, int METHOD>
+__global__ void __launch_bounds__(64, 1)
+bwd_scan_small_lds_kernel(int P, int N, const double* __restrict__ A, const double* __restrict__ dEdm,
+                          const double* __restrict__ dEdS, const double* __restrict__ jm,
+                          const int* __restrict__ obs_flag, const double* __restrict__ jumpS, int jumpS_stride,
+                          double dt, const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
+                          double* __restrict__ lam_out, double* __restrict__ Psi_out) {
+    using Tm = SmallD<D>;
+    using L = SmallLds;
+    constexpr int DD = Tm::DD, PB = L::PB, T = L::T;
+    using InM = L::In<DD>;
+    using Inv = L::In<D>;
+    using OutM = L::Out<DD>;
+    using Outv = L::Out<D>;
+    __shared__ double lds[2 * InM::LDS + 2 * Inv::LDS + OutM::LDS + Outv::LDS];
+    double* inA = lds;
+    double* inG = inA + InM::LDS;
+    double* ing = inG + InM::LDS;
+    double* inj = ing + Inv::LDS;
+    double* outP = inj + Inv::LDS;
+    double* outl = outP + OutM::LDS;
+    const int lane = threadIdx.x;
+    const int p0 = blockIdx.x * PB;
+    const bool act = lane < PB && p0 + lane < P;
+    const int pl = min(lane, PB - 1);
+    const int p = min(p0 + pl, P - 1);
+    const bool flagged = jumpS && obs_flag;
+    double jt[DD], X[DD], x[D];
+#pragma unroll
+    for (int q = 0; q < DD; ++q) {
+        jt[q] = flagged ? jumpS[(size_t)p * jumpS_stride + q] : 0.0;
+        X[q] = Psi_last ? Psi_last[(size_t)p * DD + q] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < D; ++q) x[q] = lam_last ? lam_last[(size_t)p * D + q] : 0.0;
+    // chunk c holds rows [T c, T c + T); its inputs are rows [T c - 2, T c + T): row t - 1 is needed with row t
+    const int nch = (N + T - 1) / T;
+    const int sp = min(p0 + L::prob_of(lane), P - 1);
+    const bool svalid = p0 + L::prob_of(lane) < P;
+    const long long perM = (long long)N * DD, perv = (long long)N * D;
+    const size_t baseM = (size_t)sp * perM, basev = (size_t)sp * perv;
+    double preA[2 * InM::NI], preG[2 * InM::NI], preg[2 * Inv::NI], prej[2 * Inv::NI];
+    auto fetch = [&](int c) {
+        const long long r0 = (long long)T * c - 2;
+        if (r0 >= 0 && r0 + L::R <= N) {
+            InM::template fetch<false>(A, baseM, perM, r0, lane, preA);
+            InM::template fetch<false>(dEdS, baseM, perM, r0, lane, preG);
+            Inv::template fetch<false>(dEdm, basev, perv, r0, lane, preg);
+            Inv::template fetch<false>(jm, basev, perv, r0, lane, prej);
+        } else {
+            InM::template fetch<true>(A, baseM, perM, r0, lane, preA);
+            InM::template fetch<true>(dEdS, baseM, perM, r0, lane, preG);
+            Inv::template fetch<true>(dEdm, basev, perv, r0, lane, preg);
+            Inv::template fetch<true>(jm, basev, perv, r0, lane, prej);
+        }
+    };
+    fetch(nch - 1);
+    const double* myA = inA + pl * InM::STRIDE;
+    const double* myG = inG + pl * InM::STRIDE;
+    const double* myg = ing + pl * Inv::STRIDE;
+    const double* myj = inj + pl * Inv::STRIDE;
+    double* myP = outP + pl * OutM::STRIDE;
+    double* myl = outl + pl * Outv::STRIDE;
+    for (int c = nch - 1; c >= 0; --c) {
+        InM::commit(preA, lane, inA);
+        InM::commit(preG, lane, inG);
+        Inv::commit(preg, lane, ing);
+        Inv::commit(prej, lane, inj);
+        L::fence();
+        fetch(c > 0 ? c - 1 : 0);
+        const int t0 = T * c;
+        if (act) {
+#pragma unroll
+            for (int u = T - 1; u >= 0; --u) {
+                const int t = t0 + u;
+                if (t < N) {                              // uniform: only the top chunk has rows beyond N - 1
+                    Tm::store(myP + u * DD, X);
+                    Tm::store(myl + u * D, x);
+                    if (t >= 1) {
+                        // chunk rows: row t is entry u + 2, row t - 1 entry u + 1
+                        double At[DD], Gt[DD], gt[D], Ap1[DD], Gp[DD], gp[D], jv[D];
+                        Tm::load(myA + (u + 2) * DD, At);
+                        Tm::load(myG + (u + 2) * DD, Gt);
+                        Tm::load(myg + (u + 2) * D, gt);
+                        if (METHOD != VGPA_EULER) {
+                            Tm::load(myA + (u + 1) * DD, Ap1);
+                            Tm::load(myG + (u + 1) * DD, Gp);
+                            Tm::load(myg + (u + 1) * D, gp);
+                        }
+                        Tm::load(myj + (u + 1) * D, jv);
+                        Tm::template bwd_step<METHOD>(At, Gt, gt, Ap1, Gp, gp, dt, X, x);
+                        const bool on = flagged && obs_flag[t - 1] != 0;      // core/bwd_ode.py:124,127
+#pragma unroll
+                        for (int q = 0; q < DD; ++q) X[q] += on ? jt[q] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < D; ++q) x[q] += jv[q];
+                    }
+                }
+            }
+        }
+        L::fence();
+        if (t0 + T <= N) {
+            OutM::template flush<false>(outP, Psi_out, baseM, perM, t0, svalid, lane);
+            Outv::template flush<false>(outl, lam_out, basev, perv, t0, svalid, lane);
+        } else {
+            OutM::template flush<true>(outP, Psi_out, baseM, perM, t0, svalid, lane);
+            Outv::template flush<true>(outl, lam_out, basev, perv, t0, svalid, lane);
+        }
+        L::fence();
     }
 }
 #endif  // VGPA_SMALL_D_SCANS
