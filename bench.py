@@ -150,7 +150,8 @@ def main():
     ap.add_argument("--mode", choices=("problems", "windows"), default="problems")
     ap.add_argument("--problems", type=int, default=512,
                     help="problems per GPU (mode problems) or in all (mode windows)")
-    ap.add_argument("--micro", type=int, default=4, help="micro-batches of problems (mode windows)")
+    ap.add_argument("--micro", type=int, default=None,
+                    help="micro-batches of problems (mode windows); default 4, or 1 when there is one window")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -219,7 +220,8 @@ def main():
     else:
         P_total = P
         win = batch.time_window(N, rank, world)
-        micro = max(1, min(args.micro, P))
+        # micro-batches overlap the hand-offs between windows; with one window there is nothing to overlap
+        micro = max(1, min(args.micro if args.micro else (4 if world > 1 else 1), P))
         sde = None
         ops = []
         for c in range(micro):
