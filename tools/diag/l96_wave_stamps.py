@@ -12,7 +12,7 @@ _lib.lib = dbg
 from vgpa_amd import engine
 import bench
 dev = torch.device("cuda", 0)
-D, N, dt, P = 40, 2002, 0.005, 64
+D, N, dt, P = 40, 2002, 0.005, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 A, b, sde, m0, S0, thetas = bench.synth_problem(D, N, dt, P, 1, dev)
 prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
 m, S = engine.fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=True)
@@ -22,8 +22,8 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 dbg.vgpa_debug_l96_stamps.argtypes = [ctypes.c_void_p]
 print("rc", dbg.vgpa_debug_l96_stamps(buf))
-t = np.array([buf[i] for i in (16, 17, 18, 19, 21, 22, 23, 25, 26)], dtype=np.int64)
-names = ["loads", "cholesky", "ef,base", "G+residuals", "reduce", "W", "dS+dm mfma", "dS store"]
+t = np.array([buf[i] for i in (16, 17, 18, 19, 21, 22, 23, 25, 26, 31)], dtype=np.int64)
+names = ["loads", "cholesky", "ef,base", "G+residuals", "reduce", "W", "dS+dm mfma", "dS store", "stores land"]
 for n, v in zip(names, np.diff(t)): print(f"{n:12s} {v:8d} ticks")
 print("total", t[-1] - t[0])
 c = np.array([buf[17], buf[27], buf[28], buf[29], buf[30], buf[18]], dtype=np.int64)

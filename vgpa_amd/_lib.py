@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvgpa_hip.so")
+# VGPA_HIP_LIBRARY names another build of the same library (experimental builds, profiling builds)
+LIB_PATH = os.environ.get("VGPA_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvgpa_hip.so")
 
 ABI_VERSION = 1
 

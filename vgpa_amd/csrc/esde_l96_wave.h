@@ -38,7 +38,8 @@
 //   5  Esde(t), u = v+ - v-, g
 //   6  W' = L'^-1 in place: W_IJ = -T_I sum_K L_IK W_KJ (matrix cores, one scratch tile);
 //      the part above the diagonal is zeroed
-//   7  one pass over the rows of W': dEsde/dS = W' diag(g) W and W'u on the matrix cores.
+//   7  one pass over the rows of W': dEsde/dS = W' diag(g) W on the matrix cores, W'u beside it
+//      on the vector ALU (the rows are in registers anyway).
 //      Both operands of the first are scaled by sqrt|g_k| (one with the sign of g_k), so
 //      that entry (i, j) and entry (j, i) are sums of identical products in identical
 //      order: the result is bitwise symmetric, as the symmetric backward scan requires.
@@ -75,8 +76,7 @@ __device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
 }
 
 // Cross-lane helpers.  A DPP row rotation moves data inside each row of 16 lanes on the
-// vector ALU (no LDS round trip); the sum over the four rows of 16 lanes is one matrix-core
-// instruction with an all-ones A operand (C[.][c] = sum_k B[k][c], B[k][c] = lane 16 k + c).
+// vector ALU (no LDS round trip).
 template <int CTRL>
 __device__ __forceinline__ double wv_dpp(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
@@ -92,10 +92,28 @@ __device__ __forceinline__ double wv_row_sum(double v) {
     v += wv_dpp<0x121>(v);   // row_ror:1
     return v;
 }
-// sum over lanes with equal (lane & 15), in every lane
+// sum over lanes with equal (lane & 15), in every lane: the two halves of the wavefront are
+// added (v_permlane32_swap hands every lane both halves' values), then the even and odd rows of
+// 16 lanes (v_permlane16_swap).  Six vector instructions; a matrix-core instruction with an
+// all-ones operand does the same sum but holds the SIMD for 64 cycles.
 __device__ __forceinline__ double wv_col_sum(double v) {
+#ifdef VGPA_COLSUM_MFMA
     const wv_f64x4 z = {0.0, 0.0, 0.0, 0.0};
     return wv_mfma(1.0, v, z)[0];
+#endif
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return v;
 }
 
 // v_mov_b64 / v_fmac_f64 with the DPP control row_newbcast:N take their first source from
@@ -361,11 +379,6 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         double* dst = tile_ptr(I, K);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q * LD] = t[q];
-    };
-    auto tile_zero = [&](int I, int K) {
-        double* dst = tile_ptr(I, K);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q * LD] = 0.0;
     };
     bool ok = wv_factor_diag<0>(buf, dump, zslot, lane);
     WV_STAMP(27);
@@ -733,8 +746,8 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         for (int s = 0; s < 2; ++s) w20 = wv_mfma(nt2[s], xb[s], w20);
         wave_lds_fence();
         tile_wr(2, 0, w20);
-        // diagonal blocks: W_JJ = T_J, from the shifted upper triangle to its place; everything
-        // above the diagonal of W becomes zero, so that the products below need no masks
+        // diagonal blocks: W_JJ = T_J, from the shifted upper triangle to its place, with zeros above
+        // the diagonal (the blocks of W above the diagonal blocks are never read)
         const int ra = lane >> 2, cb = 4 * (lane & 3);
         double t[3][4];
 #pragma unroll
@@ -757,9 +770,6 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
             *reinterpret_cast<double2*>(dst) = make_double2(t[2][0], t[2][1]);
             *reinterpret_cast<double2*>(dst + 2) = make_double2(t[2][2], t[2][3]);
         }
-        tile_zero(0, 1);
-        tile_zero(0, 2);
-        tile_zero(1, 2);
     }
     wave_lds_fence();
 
@@ -770,46 +780,41 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     // One pass over the rows k of W.  Columns 40..47 of a row are whatever follows in LDS
     // (finite numbers): they only reach the padded rows / columns of the results.
     {
-        wv_f64x4 acc[3][3], ym[3];
+        wv_f64x4 acc[3][3];
+        double yv[3] = {0.0, 0.0, 0.0};       // W'u of column 16 t + pi, this lane group's rows k
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            ym[i] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
         }
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             const int k = 4 * s + g4;
-            const double sa = sav[k], sb = sbv[k];
-            const double ub = (c16 == 0) ? uv[k] : 0.0;      // u as column 0 of a B operand
+            const double sa = sav[k], sb = sbv[k], uk = uv[k];
             const int nt = s / 4 + 1;                        // column blocks 0 .. nt-1 reach row k
-            double wa[3], ao[3], bo[3];
+            double ao[3], bo[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 if (t < nt) {
-                    wa[t] = buf[k * LD + 16 * t + pi];
-                    ao[t] = sa * wa[t];
+                    const double wa = buf[k * LD + 16 * t + pi];
+                    yv[t] = fma(wa, uk, yv[t]);
+                    ao[t] = sa * wa;
                     bo[t] = sb * buf[k * LD + 16 * t + c16];
                 }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                if (i < nt) ym[i] = wv_mfma(wa[i], ub, ym[i]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     if (i < nt && j <= i) acc[i][j] = wv_mfma(ao[i], bo[j], acc[i][j]);
             }
         }
-        // (W' u)[16 i + 4 g4 + q] sits in register q of the lanes with c16 == 0
-        wave_lds_fence();
-        if (c16 == 0) {
+        // dEsde/dm = (w c / 2) W' u, W = sqrt(c2) W': the first lane group holds row 16 t + pi
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) basev[16 * i + 4 * g4 + q] = ym[i][q];
+        for (int t = 0; t < 3; ++t) {
+            const double y = wv_col_sum(yv[t]);
+            if (g4 == 0 && 16 * t + pi < D) a.dEdm[e * D + 16 * t + pi] = 0.5 * w1 * c2 * y;
         }
-        wave_lds_fence();
-        if (lane < D) a.dEdm[e * D + lane] = 0.5 * w1 * c2 * basev[lane];      // (w c / 2) W' u, W = sqrt(c2) W'
     WV_STAMP(25);
         double* Gd = a.dEdS + e * DD;
             // The result is bitwise symmetric, so only the tiles on and below the diagonal are formed.
@@ -833,5 +838,9 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
                 }
     }
     WV_STAMP(26);
+#ifdef VGPA_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);            // how long the wavefront stays resident for its stores
+    WV_STAMP(31);
+#endif
 #undef WV_RELANE
 }
