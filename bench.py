@@ -35,7 +35,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64, vector and matrix alike
 ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false>"
+KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel", "esde": ESDE_KERNEL,
+                "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
 
 
@@ -170,12 +173,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # VGPA_BENCH_FORCE_DIST=1 runs a single rank through the RCCL communicator too (a rehearsal of the
+    # collectives on a one-GPU box)
+    force_dist = world == 1 and os.environ.get("VGPA_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from vgpa_amd import batch, engine, _lib
-    comm = batch.DistComm() if world > 1 else batch.SingleComm()
+    comm = batch.DistComm() if dist is not None else batch.SingleComm()
 
     events = {k: [] for k in ("fwd_scan", "esde", "bwd_scan_grad")}
 
@@ -303,6 +312,20 @@ def main():
                                 "traffic": None if traffic_unit is None else traffic_unit * units_per_launch,
                                 "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if traffic_unit is not None else None,
                                 "bytes_per_unit": bytes_per_unit, "avg_ms": esde_ms}
+            # The energy kernel against the other roof: about 170 kflop of FP64 arithmetic per unit
+            # (factorisation D^3/3, A L' D^3, inverse D^3/3, W' diag(g) W D^3/3, 20 flop for each of the
+            # D^2 sigma-point residual entries) against the 78.6 TFLOP/s FP64 peak.
+            flops_per_unit = 170e3
+            tf = units_per_launch * flops_per_unit / (esde_ms * 1e-3) / 1e12
+            line["roofline"]["fp64"] = {"flops_per_unit": flops_per_unit, "achieved_TFLOPs": tf, "peak": FP64_PEAK_TFLOPS,
+                                        "frac": tf / FP64_PEAK_TFLOPS}
+            # the kernel with the largest share of the step
+            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+            dom_traffic = measured_traffic_per_unit(KERNEL_NAMES[dom])
+            line["roofline_dominant"] = {"kernel": KERNEL_NAMES[dom], "bound": "hbm", "achieved": kernels[dom]["achieved_GBps"],
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
+                                         "traffic": None if dom_traffic is None else dom_traffic * units_per_launch,
+                                         "bytes_per_unit": per_unit[dom], "avg_ms": kernels[dom]["avg_ms"]}
             line["kernels"] = kernels
         else:
             line["config"] = {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
