@@ -54,6 +54,48 @@ def test_free_energy_and_gradient_vs_golden(system, fname, method):
             assert relerr(mParam[key], g[name]) <= TOL, key
 
 
+def test_gradient_uses_published_state_only_while_it_is_current():
+    """gradL_Ab right after varFreeEnergy takes m, S, lam, Psi, <f>, <df/dx> from the device; fresh
+    array objects, edited values or another point x must send it back to the arrays in mParam."""
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core.gradL_Ab import gradL_Ab
+    from vgpa_amd.core import _facade
+    g = load_golden("sys_l63_ut.npz")
+    sde = sde_from_golden(g, "EULER")
+    m0, S0 = initial_moments(g)
+    mParam = dict(m0=m0, S0=S0, fun=_dyn("l63_ut").energy_mode, sde_struct=sde)
+    Ab = np.array(g["Ab"], copy=True)
+    varFreeEnergy(Ab, mParam)
+    keys = _facade.PUBLISHED_KEYS
+    assert _facade.recall_published(mParam, *_dev_Ab(Ab, sde)) is not None
+    g0 = gradL_Ab(Ab, mParam)
+    assert relerr(g0, g["EULER.grad"]) <= TOL
+    # the same numbers as new objects: upload path, identical result
+    fresh = dict(mParam)
+    for k in keys:
+        fresh[k] = np.array(mParam[k], copy=True)
+    assert _facade.recall_published(fresh, *_dev_Ab(Ab, sde)) is None
+    assert np.array_equal(gradL_Ab(Ab, fresh), g0)
+    # edited values are honoured
+    fresh["lamt"][3] += 0.5
+    g1 = gradL_Ab(Ab, fresh)
+    assert not np.array_equal(g1, g0)
+    # the published arrays are read-only, so they cannot drift away from the device copy
+    with pytest.raises(ValueError):
+        mParam["mt"][0] = 0.0
+    # another point with the old arrays (what the reference would compute from them)
+    Ab2 = Ab * 1.01
+    assert _facade.recall_published(mParam, *_dev_Ab(Ab2, sde)) is None
+    want = gradL_Ab(Ab2, {**mParam, **{k: np.array(mParam[k], copy=True) for k in keys}})
+    assert np.array_equal(gradL_Ab(Ab2, mParam), want)
+
+
+def _dev_Ab(Ab, sde):
+    from vgpa_amd.core import _facade
+    A, b = _facade.unpack_Ab(Ab, sde["N"], sde["D"])
+    return _facade.dev_batch1(A, sde["D"], "m"), _facade.dev_batch1(b, sde["D"], "v")
+
+
 @pytest.mark.parametrize("system,fname", SYSTEMS)
 def test_energy_mode_vs_golden(system, fname):
     g = load_golden(fname)

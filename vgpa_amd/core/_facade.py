@@ -52,13 +52,74 @@ def dev_batch1(x, D, kind):
     return engine.to_dev(x.reshape(shp))
 
 
+def to_host(tensors):
+    """Device tensors -> NumPy arrays, through page-locked host buffers: the copies run at
+    PCIe speed (a pageable destination is staged at a few GB/s) and are queued together with
+    one synchronisation at the end.  The arrays own their buffers (through the tensor they
+    are views of); torch's host allocator recycles a buffer once its array is dropped."""
+    import torch
+    host = []
+    for t in tensors:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        host.append(h)
+    torch.cuda.current_stream().synchronize()
+    return [h.numpy() for h in host]
+
+
 def host_vec(t, D):
     """Device (1,N,D) / (1,N) -> NumPy (N,D) / (N,1)."""
-    a = t[0].cpu().numpy()
+    a = to_host([t[0]])[0]
     return a.reshape(-1, 1) if D == 1 else a
 
 
 def host_mat(t, D):
     """Device (1,N,D,D) / (1,N) -> NumPy (N,D,D) / (N,1)."""
-    a = t[0].cpu().numpy()
+    a = to_host([t[0]])[0]
     return a.reshape(-1, 1) if D == 1 else a
+
+
+# ---------------------------------------------------------------------------
+# The device state behind the arrays varFreeEnergy last published.  The reference's
+# optimisers call gradL_Ab(x, mParam) right after varFreeEnergy(x, mParam); when the six
+# arrays in mParam are still the very objects published (and unchanged, and x is the same
+# point), gradL_Ab takes m, S, lam, Psi, <f>, <df/dx> from the device instead of uploading
+# them again.
+# ---------------------------------------------------------------------------
+PUBLISHED_KEYS = ("mt", "St", "Efx", "Edf", "lamt", "Psit")
+_published = None
+
+
+def _fingerprint(a):
+    """A strided sample of an array (64 values), to notice in-place changes cheaply."""
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 64)
+    return flat[::step][:64].tobytes()
+
+
+def remember_published(mParam, prob, Ad, bd, st):
+    """Called by varFreeEnergy after it has put the six arrays into ``mParam``.  The arrays are
+    made read-only: code that wants to edit them takes a copy (as the reference's drivers do
+    with deepcopy), and a copy is a different object, which sends gradL_Ab down the upload path."""
+    global _published
+    for k in PUBLISHED_KEYS:
+        mParam[k].flags.writeable = False
+    _published = dict(arrays={k: mParam[k] for k in PUBLISHED_KEYS},
+                      prints={k: _fingerprint(mParam[k]) for k in PUBLISHED_KEYS},
+                      prob=prob, Ad=Ad, bd=bd, st=st, sde=mParam["sde_struct"], fun=mParam["fun"])
+
+
+def recall_published(mParam, Ad, bd):
+    """The cached (problem, state) if ``mParam`` still holds what was published for the
+    point (Ad, bd); None otherwise."""
+    import torch
+    c = _published
+    if c is None or mParam.get("sde_struct") is not c["sde"] or mParam.get("fun") is not c["fun"]:
+        return None
+    for k in PUBLISHED_KEYS:
+        a = mParam.get(k)
+        if a is not c["arrays"][k] or _fingerprint(a) != c["prints"][k]:
+            return None
+    if Ad.shape != c["Ad"].shape or not (torch.equal(Ad, c["Ad"]) and torch.equal(bd, c["bd"])):
+        return None
+    return c["prob"], c["st"]

@@ -26,12 +26,19 @@ def gradL_Ab(Ab, mParam, evalF=False, outer=False):
         m, S, lam, Psi, Ef, Edf = st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf
     else:
         A, b = _facade.unpack_Ab(Ab, N, D)
-        prob = engine.make_problem(_facade.system_of(mParam["fun"]), sde, mParam["m0"], mParam["S0"], P=1)
         Ad, bd = _facade.dev_batch1(A, D, "m"), _facade.dev_batch1(b, D, "v")
-        m, lam, Ef = (_facade.dev_batch1(mParam[k], D, "v") for k in ("mt", "lamt", "Efx"))
-        S, Psi, Edf = (_facade.dev_batch1(mParam[k], D, "m") for k in ("St", "Psit", "Edf"))
-    gLA, gLb = engine.grad_assemble(prob, Ad, bd, m, S, lam, Psi, Ef, Edf, outer=outer)
-    out = np.empty((gLA.numel() + gLb.numel(), 1), dtype=np.float64)
-    out[:gLA.numel(), 0] = gLA.reshape(-1).cpu().numpy()
-    out[gLA.numel():, 0] = gLb.reshape(-1).cpu().numpy()
-    return out
+        cached = _facade.recall_published(mParam, Ad, bd)
+        if cached is not None:
+            # the arrays in mParam are the ones varFreeEnergy just published for this point
+            prob, st = cached
+            m, S, lam, Psi, Ef, Edf = st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf
+        else:
+            prob = engine.make_problem(_facade.system_of(mParam["fun"]), sde, mParam["m0"], mParam["S0"], P=1)
+            m, lam, Ef = (_facade.dev_batch1(mParam[k], D, "v") for k in ("mt", "lamt", "Efx"))
+            S, Psi, Edf = (_facade.dev_batch1(mParam[k], D, "m") for k in ("St", "Psit", "Edf"))
+    import torch
+    nA, nb = (N, N) if D == 1 else (N * D * D, N * D)
+    flat = torch.empty(nA + nb, dtype=torch.float64, device=Ad.device)
+    engine.grad_assemble(prob, Ad, bd, m, S, lam, Psi, Ef, Edf, outer=outer,
+                         out=(flat[:nA].view(Ad.shape), flat[nA:].view(bd.shape)))
+    return _facade.to_host([flat])[0].reshape(-1, 1)

@@ -26,12 +26,10 @@ def _evaluate(Ab, mParam, want_hyper=False):
 def _publish(mParam, st, D):
     """The side effects of the reference (core/varFreeEnergy.py:84-104): host arrays
     that drivers index and deep-copy."""
-    mParam["mt"] = _facade.host_vec(st.m, D)
-    mParam["St"] = _facade.host_mat(st.S, D)
-    mParam["Efx"] = _facade.host_vec(st.Ef, D)
-    mParam["Edf"] = _facade.host_mat(st.Edf, D)
-    mParam["lamt"] = _facade.host_vec(st.lam, D)
-    mParam["Psit"] = _facade.host_mat(st.Psi, D)
+    keys = ("mt", "St", "Efx", "Edf", "lamt", "Psit")
+    host = _facade.to_host([t[0] for t in (st.m, st.S, st.Ef, st.Edf, st.lam, st.Psi)])
+    for k, a in zip(keys, host):
+        mParam[k] = a.reshape(-1, 1) if D == 1 else a
 
 
 def varFreeEnergy(Ab, mParam):
@@ -41,8 +39,10 @@ def varFreeEnergy(Ab, mParam):
     receives 'mt', 'St', 'Efx', 'Edf', 'lamt', 'Psit' as NumPy arrays.  Returns a
     Python float (core/varFreeEnergy.py:111).
     """
-    prob, _, _, st = _evaluate(Ab, mParam)
+    prob, Ad, bd, st = _evaluate(Ab, mParam)
     _publish(mParam, st, prob.D)
+    if prob.system >= 0:
+        _facade.remember_published(mParam, prob, Ad, bd, st)
     return float(st.F[0].item())
 
 
