@@ -904,6 +904,14 @@ bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, con
     if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && METHOD != VGPA_RK4) {
         // 16-byte pieces through LDS, sixteen problems per wavefront
         const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
+        if constexpr (METHOD == VGPA_EULER) {
+            // a row of the state per lane
+            const size_t lds = sizeof(double) * SmallRows::fwd_lds_doubles(D);
+            if (D == 2) allow_lds(fwd_scan_small_rows_kernel<2>, lds); else allow_lds(fwd_scan_small_rows_kernel<3>, lds);
+            if (D == 2) hipLaunchKernelGGL(fwd_scan_small_rows_kernel<2>, dim3(gl), dim3(SmallRows::NT), lds, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
+            else hipLaunchKernelGGL(fwd_scan_small_rows_kernel<3>, dim3(gl), dim3(SmallRows::NT), lds, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
+            return true;
+        }
 #define VGPA_FL(DD_) hipLaunchKernelGGL((fwd_scan_small_lds_kernel<DD_, METHOD>), dim3(gl), dim3(64), 0, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
         if (D == 2) VGPA_FL(2); else VGPA_FL(3);
 #undef VGPA_FL
@@ -922,6 +930,13 @@ bool launch_bwd_small(int P, int N, int D, const double* A, const double* dEdm, 
                       const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
     if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && !jS) {
         const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
+        if constexpr (METHOD == VGPA_EULER) {
+            const size_t lds = sizeof(double) * SmallRows::bwd_lds_doubles(D);
+            if (D == 2) allow_lds(bwd_scan_small_rows_kernel<2>, lds); else allow_lds(bwd_scan_small_rows_kernel<3>, lds);
+            if (D == 2) hipLaunchKernelGGL(bwd_scan_small_rows_kernel<2>, dim3(gl), dim3(SmallRows::NT), lds, st, P, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+            else hipLaunchKernelGGL(bwd_scan_small_rows_kernel<3>, dim3(gl), dim3(SmallRows::NT), lds, st, P, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+            return true;
+        }
 #define VGPA_BL(DD_) hipLaunchKernelGGL((bwd_scan_small_lds_kernel<DD_, METHOD>), dim3(gl), dim3(64), 0, st, P, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out)
         if (D == 2) VGPA_BL(2); else VGPA_BL(3);
 #undef VGPA_BL

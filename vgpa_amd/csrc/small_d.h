@@ -642,6 +642,319 @@ bwd_scan_small_lds_kernel(int P, int N, const double* __restrict__ A, const doub
         L::fence();
     }
 }
+// ---------------------------------------------------------------------------
+// Euler scans with a ROW of the state per lane.
+//
+// With a whole problem per lane the time of the kernels above is the dependent FP64 chain of
+// one lane (about a hundred instructions per step for D = 3).  Here the four lanes that stage
+// a problem's chunk also integrate it: lane i of the quad keeps row i of S (or Psi) and entry
+// i of m (or lam), rebuilds the whole state from the rows of its neighbours with DPP quad
+// broadcasts at the start of a step, and computes its row of the next state -- a third of the
+// arithmetic per lane, all 64 lanes busy.  Same products in the same order as SmallD::fwd_step /
+// bwd_step for Euler, so the results are the same bits.  Lanes D .. 3 of a quad repeat row D - 1.
+// ---------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = R | (R << 2) | (R << 4) | (R << 6);      // quad_perm:[R,R,R,R]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int D, int R>
+struct QuadGather {
+    // full[r][:] = row held by lane r of the quad, v[r] = scalar held by lane r
+    static __device__ __forceinline__ void run(const double (&row)[D], double s, double (&full)[D * D], double (&v)[D]) {
+        if constexpr (R < D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) full[R * D + j] = quad_bcast<R>(row[j]);
+            v[R] = quad_bcast<R>(s);
+            QuadGather<D, R + 1>::run(row, s, full, v);
+        }
+    }
+};
+
+// A workgroup is two wavefronts: the first integrates, the second moves the data -- it keeps the
+// inputs of the next DEPTH chunks in flight in its registers, commits a chunk to one of two LDS
+// buffers while the first wavefront integrates out of the other, and writes the finished chunk of
+// results out of a second pair of buffers.  One barrier per chunk.
+struct SmallRows {
+    static constexpr int NT = 128;
+    static constexpr int DEPTH_FWD = 3, DEPTH_BWD = 2;    // chunks in flight
+    static constexpr int in_lds(int rd) { return SmallLds::PB * ((SmallLds::R * rd) | 1); }
+    static constexpr int out_lds(int rd) { return SmallLds::PB * ((SmallLds::T * rd) | 1); }
+    static constexpr int fwd_lds_doubles(int D) { return 2 * (in_lds(D * D) + in_lds(D)) + 2 * (out_lds(D * D) + out_lds(D)); }
+    static constexpr int bwd_lds_doubles(int D) { return 4 * (in_lds(D * D) + in_lds(D)) + 2 * (out_lds(D * D) + out_lds(D)); }
+};
+
+template <int D>
+__global__ void __launch_bounds__(SmallRows::NT, 1)
+fwd_scan_small_rows_kernel(int P, int N, const double* __restrict__ A, const double* __restrict__ b,
+                           const double* __restrict__ m0, const double* __restrict__ S0,
+                           const double* __restrict__ Sigma, int sigma_stride, double dt,
+                           double* __restrict__ m_out, double* __restrict__ S_out) {
+    using Tm = SmallD<D>;
+    using L = SmallLds;
+    constexpr int DD = Tm::DD, PB = L::PB, T = L::T, DEPTH = SmallRows::DEPTH_FWD;
+    using InA = L::In<DD>;
+    using Inb = L::In<D>;
+    using OutS = L::Out<DD>;
+    using Outm = L::Out<D>;
+    constexpr int IN = InA::LDS + Inb::LDS, OUT = OutS::LDS + Outm::LDS;
+    extern __shared__ double lds[];                    // 2 IN + 2 OUT doubles: SmallRows::fwd_lds_doubles(D)
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int p0 = blockIdx.x * PB;
+    const int pl = L::prob_of(lane);
+    const int sp = min(p0 + pl, P - 1);
+    const int nch = (N + T - 1) / T;
+    if (role == 1) {
+        // ---- data movement ----
+        const bool svalid = p0 + pl < P;
+        const long long perA = (long long)N * DD, perb = (long long)N * D;
+        const size_t baseA = (size_t)sp * perA, baseb = (size_t)sp * perb;
+        double preA[DEPTH][2 * InA::NI], preb[DEPTH][2 * Inb::NI];
+        auto fetch = [&](int c, double (&pa)[2 * InA::NI], double (&pb)[2 * Inb::NI]) {
+            const long long r0 = (long long)T * min(c, nch - 1);
+            if (r0 + L::R <= N) {
+                InA::template fetch<false>(A, baseA, perA, r0, lane, pa);
+                Inb::template fetch<false>(b, baseb, perb, r0, lane, pb);
+            } else {
+                InA::template fetch<true>(A, baseA, perA, r0, lane, pa);
+                Inb::template fetch<true>(b, baseb, perb, r0, lane, pb);
+            }
+        };
+        auto flush = [&](int c) {
+            const double* out = lds + 2 * IN + (c & 1) * OUT;
+            const int t0 = T * c;
+            if (t0 + T <= N) {
+                OutS::template flush<false>(out, S_out, baseA, perA, t0, svalid, lane);
+                Outm::template flush<false>(out + OutS::LDS, m_out, baseb, perb, t0, svalid, lane);
+            } else {
+                OutS::template flush<true>(out, S_out, baseA, perA, t0, svalid, lane);
+                Outm::template flush<true>(out + OutS::LDS, m_out, baseb, perb, t0, svalid, lane);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, preA[d], preb[d]);
+        for (int c0 = 0; c0 < nch; c0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int c = c0 + d;
+                if (c < nch) {
+                    double* in = lds + (c & 1) * IN;
+                    InA::commit(preA[d], lane, in);
+                    Inb::commit(preb[d], lane, in + InA::LDS);
+                    fetch(c + DEPTH, preA[d], preb[d]);
+                    __syncthreads();                  // chunk c is in LDS; the results of chunk c - 1 are complete
+                    if (c >= 1) flush(c - 1);
+                }
+            }
+        }
+        __syncthreads();
+        flush(nch - 1);
+        return;
+    }
+    // ---- integration: lane i of a quad holds row i of S and entry i of m ----
+    const int i = min(L::sub_of(lane), D - 1);
+    double Sgr[D], Sr[D], mi;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        Sgr[j] = Sigma[(size_t)sp * sigma_stride + i * D + j];
+        Sr[j] = S0[(size_t)sp * DD + i * D + j];
+    }
+    mi = m0[(size_t)sp * D + i];
+    for (int c = 0; c < nch; ++c) {
+        const double* myA = lds + (c & 1) * IN + pl * InA::STRIDE;
+        const double* myb = lds + (c & 1) * IN + InA::LDS + pl * Inb::STRIDE + i;
+        double* myS = lds + 2 * IN + (c & 1) * OUT + pl * OutS::STRIDE + i * D;
+        double* mym = lds + 2 * IN + (c & 1) * OUT + OutS::LDS + pl * Outm::STRIDE + i;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+            // row T c + u is the current state; then one step with row u of the chunk
+#pragma unroll
+            for (int j = 0; j < D; ++j) myS[u * DD + j] = Sr[j];
+            mym[u * D] = mi;
+            double S[DD], m[D], At[DD], ai[D];
+            QuadGather<D, 0>::run(Sr, mi, S, m);
+            Tm::load(myA + u * DD, At);
+#pragma unroll
+            for (int k = 0; k < D; ++k) ai[k] = myA[u * DD + i * D + k];
+            const double bi = myb[u * D];
+            // row i of  S + dt (Sig - A S - S A')  and entry i of  m + dt (-A m + b)   (core/fwd_ode.py:121-131)
+            double Sn[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    s1 = fma(ai[k], S[k * D + j], s1);
+                    s2 = fma(Sr[k], At[j * D + k], s2);
+                }
+                const double K = -s1 - s2 + Sgr[j];
+                Sn[j] = Sr[j] + dt * K;
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s = fma(ai[k], m[k], s);
+            const double f = -s + bi;
+            mi = mi + dt * f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) Sr[j] = Sn[j];
+        }
+    }
+    __syncthreads();
+}
+
+template <int D>
+__global__ void __launch_bounds__(SmallRows::NT, 1)
+bwd_scan_small_rows_kernel(int P, int N, const double* __restrict__ A, const double* __restrict__ dEdm,
+                           const double* __restrict__ dEdS, const double* __restrict__ jm,
+                           const int* __restrict__ obs_flag, const double* __restrict__ jumpS, int jumpS_stride,
+                           double dt, const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
+                           double* __restrict__ lam_out, double* __restrict__ Psi_out) {
+    using Tm = SmallD<D>;
+    using L = SmallLds;
+    constexpr int DD = Tm::DD, PB = L::PB, T = L::T, DEPTH = SmallRows::DEPTH_BWD;
+    using InM = L::In<DD>;
+    using Inv = L::In<D>;
+    using OutM = L::Out<DD>;
+    using Outv = L::Out<D>;
+    constexpr int IN = 2 * InM::LDS + 2 * Inv::LDS, OUT = OutM::LDS + Outv::LDS;
+    extern __shared__ double lds[];                    // 2 IN + 2 OUT doubles: SmallRows::bwd_lds_doubles(D)
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int p0 = blockIdx.x * PB;
+    const int pl = L::prob_of(lane);
+    const int sp = min(p0 + pl, P - 1);
+    // chunk c holds rows [T c, T c + T); its inputs are rows [T c - 2, T c + T): row t - 1 is needed with row t.
+    // The chunks are visited from the last to the first: visit v is chunk nch - 1 - v.
+    const int nch = (N + T - 1) / T;
+    if (role == 1) {
+        // ---- data movement ----
+        const bool svalid = p0 + pl < P;
+        const long long perM = (long long)N * DD, perv = (long long)N * D;
+        const size_t baseM = (size_t)sp * perM, basev = (size_t)sp * perv;
+        double preA[DEPTH][2 * InM::NI], preG[DEPTH][2 * InM::NI], preg[DEPTH][2 * Inv::NI], prej[DEPTH][2 * Inv::NI];
+        auto fetch = [&](int v, double (&pa)[2 * InM::NI], double (&pg)[2 * InM::NI], double (&pv)[2 * Inv::NI],
+                         double (&pj)[2 * Inv::NI]) {
+            const int c = max(nch - 1 - v, 0);
+            const long long r0 = (long long)T * c - 2;
+            if (r0 >= 0 && r0 + L::R <= N) {
+                InM::template fetch<false>(A, baseM, perM, r0, lane, pa);
+                InM::template fetch<false>(dEdS, baseM, perM, r0, lane, pg);
+                Inv::template fetch<false>(dEdm, basev, perv, r0, lane, pv);
+                Inv::template fetch<false>(jm, basev, perv, r0, lane, pj);
+            } else {
+                InM::template fetch<true>(A, baseM, perM, r0, lane, pa);
+                InM::template fetch<true>(dEdS, baseM, perM, r0, lane, pg);
+                Inv::template fetch<true>(dEdm, basev, perv, r0, lane, pv);
+                Inv::template fetch<true>(jm, basev, perv, r0, lane, pj);
+            }
+        };
+        auto flush = [&](int v) {
+            const double* out = lds + 2 * IN + (v & 1) * OUT;
+            const int t0 = T * (nch - 1 - v);
+            if (t0 + T <= N) {
+                OutM::template flush<false>(out, Psi_out, baseM, perM, t0, svalid, lane);
+                Outv::template flush<false>(out + OutM::LDS, lam_out, basev, perv, t0, svalid, lane);
+            } else {
+                OutM::template flush<true>(out, Psi_out, baseM, perM, t0, svalid, lane);
+                Outv::template flush<true>(out + OutM::LDS, lam_out, basev, perv, t0, svalid, lane);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, preA[d], preG[d], preg[d], prej[d]);
+        for (int v0 = 0; v0 < nch; v0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int v = v0 + d;
+                if (v < nch) {
+                    double* in = lds + (v & 1) * IN;
+                    InM::commit(preA[d], lane, in);
+                    InM::commit(preG[d], lane, in + InM::LDS);
+                    Inv::commit(preg[d], lane, in + 2 * InM::LDS);
+                    Inv::commit(prej[d], lane, in + 2 * InM::LDS + Inv::LDS);
+                    fetch(v + DEPTH, preA[d], preG[d], preg[d], prej[d]);
+                    __syncthreads();
+                    if (v >= 1) flush(v - 1);
+                }
+            }
+        }
+        __syncthreads();
+        flush(nch - 1);
+        return;
+    }
+    // ---- integration: lane i of a quad holds row i of Psi and entry i of lam ----
+    const int i = min(L::sub_of(lane), D - 1);
+    const bool flagged = jumpS && obs_flag;
+    double jtr[D], Xr[D], xi;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        jtr[j] = flagged ? jumpS[(size_t)sp * jumpS_stride + i * D + j] : 0.0;
+        Xr[j] = Psi_last ? Psi_last[(size_t)sp * DD + i * D + j] : 0.0;
+    }
+    xi = lam_last ? lam_last[(size_t)sp * D + i] : 0.0;
+    for (int v = 0; v < nch; ++v) {
+        const double* in = lds + (v & 1) * IN;
+        const double* myA = in + pl * InM::STRIDE;
+        const double* myG = in + InM::LDS + pl * InM::STRIDE + i * D;
+        const double* myg = in + 2 * InM::LDS + pl * Inv::STRIDE + i;
+        const double* myj = in + 2 * InM::LDS + Inv::LDS + pl * Inv::STRIDE + i;
+        double* myP = lds + 2 * IN + (v & 1) * OUT + pl * OutM::STRIDE + i * D;
+        double* myl = lds + 2 * IN + (v & 1) * OUT + OutM::LDS + pl * Outv::STRIDE + i;
+        const int t0 = T * (nch - 1 - v);
+        __syncthreads();
+#pragma unroll
+        for (int u = T - 1; u >= 0; --u) {
+            const int t = t0 + u;
+            if (t < N) {                              // uniform: only the top chunk has rows beyond N - 1
+#pragma unroll
+                for (int j = 0; j < D; ++j) myP[u * DD + j] = Xr[j];
+                myl[u * D] = xi;
+                if (t >= 1) {
+                    // chunk rows: row t is entry u + 2, row t - 1 entry u + 1
+                    double X[DD], x[D], At[DD], ari[D], aci[D], Gi[D];
+                    QuadGather<D, 0>::run(Xr, xi, X, x);
+                    Tm::load(myA + (u + 2) * DD, At);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        ari[k] = myA[(u + 2) * DD + i * D + k];
+                        aci[k] = myA[(u + 2) * DD + k * D + i];
+                        Gi[k] = myG[(u + 2) * DD + k];
+                    }
+                    const double gi = myg[(u + 2) * D];
+                    const double jvi = myj[(u + 1) * D];
+                    // row i of  Psi - dt (-G + Psi A + A' Psi)  and entry i of  lam - dt (-g + A lam)   (core/bwd_ode.py:117-127)
+                    const double ndt = -dt;
+                    const bool on = flagged && obs_flag[t - 1] != 0;
+                    double Xn[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            s1 = fma(Xr[k], At[k * D + j], s1);
+                            s2 = fma(aci[k], X[k * D + j], s2);
+                        }
+                        const double K = -Gi[j] + (s1 + s2);
+                        Xn[j] = Xr[j] + ndt * K;
+                        Xn[j] += on ? jtr[j] : 0.0;
+                    }
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s = fma(ari[k], x[k], s);
+                    const double f = -gi + s;
+                    xi = xi + ndt * f;
+                    xi += jvi;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Xr[j] = Xn[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
 #endif  // VGPA_SMALL_D_SCANS
 
 #ifdef VGPA_SMALL_D_GRAD
