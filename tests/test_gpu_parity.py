@@ -144,6 +144,35 @@ def test_scans_vs_oracle_random_inputs(D, method):
     assert relerr(lam, lr) <= TOL and relerr(Psi, Pr) <= TOL
 
 
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("N", [1, 2, 9, 2049, 2050, 5001, 20000])
+def test_one_dimensional_prefix_scans_vs_sequential_oracle(method, N):
+    """The D = 1 scans are parallel prefix computations over tiles of 2048 steps (one step short of,
+    exactly at and one step past a tile boundary; several tiles); the oracle walks the rows one by
+    one as the reference does.  Sparse jumps in the variance sequence as the smoother produces them."""
+    from vgpa_amd import engine, _lib
+    rng = np.random.default_rng(7 * N + len(method))
+    P, dt = 3, 0.01
+    A = 2.0 + 0.5 * rng.standard_normal((P, N))
+    b = rng.standard_normal((P, N))
+    m0, S0 = rng.standard_normal(P), 0.2 + rng.random(P)
+    Sig = 0.5 + rng.random(P)
+    gm, gS, jm = rng.standard_normal((P, N)), rng.standard_normal((P, N)), rng.standard_normal((P, N))
+    flag = (rng.random(N) < 0.05).astype(np.int32)
+    jval = rng.standard_normal(P)
+    d = engine.to_dev
+    import torch
+    m, S = engine.fwd_scan(_lib.METHODS[method], d(A), d(b), d(m0), d(S0), d(Sig), dt)
+    lam, Psi = engine.bwd_scan(_lib.METHODS[method], d(A), d(gm), d(gS), d(jm), dt,
+                               obs_flag=torch.from_numpy(flag).to(engine.device()), jumpS=d(jval))
+    for p in range(P):
+        mr, Sr = orc.fwd_scan(A[p][:, None], b[p][:, None], m0[p:p + 1], float(S0[p]), float(Sig[p]), dt, method)
+        jS = (flag * jval[p])[:, None]
+        lr, Pr = orc.bwd_scan(A[p][:, None], gm[p][:, None], gS[p][:, None], jm[p][:, None], jS, dt, method)
+        for got, want in ((m[p], mr), (S[p], Sr), (lam[p], lr), (Psi[p], Pr)):
+            assert relerr(got.cpu().numpy().reshape(-1), np.asarray(want).reshape(-1)) <= 1e-11
+
+
 def test_unknown_method_raises_like_the_reference():
     from vgpa_amd.core import fwd_ode, bwd_ode
     A, b = np.ones((5, 1)), np.ones((5, 1))

@@ -1,9 +1,10 @@
 // Forward moment scans m(t), S(t) and backward multiplier scans lam(t), Psi(t)
 // for gfx950.
 //
-// The recurrences are sequential in time, so parallelism comes from the batch of
-// independent problems (one workgroup per problem for D > 1, one lane per problem
-// for D == 1) and from the D x D matrix products inside a step.
+// For D > 1 the recurrences are sequential in time, so parallelism comes from the batch of
+// independent problems (one workgroup per problem; D = 2, 3: sixteen problems per wavefront,
+// small_d.h) and from the D x D matrix products inside a step.  For D == 1 a step is an affine
+// map of a scalar and the scan is a parallel prefix computation (scan_1d_prefix.h).
 //
 // n-D layout inside a workgroup: every thread owns one 2 x 4 tile of the D x D
 // state (S or Psi) and keeps it, and its Runge-Kutta increments, in registers for
@@ -726,133 +727,7 @@ bwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* _
     }
 }
 
-// ---------------------------------------------------------------------------
-// D == 1: one lane per problem.  core/fwd_ode.py: euler_1D :135, heun_1D :247,
-// rk2_1D :367, rk4_1D :493;  core/bwd_ode.py: euler_1D :132, heun_1D :241,
-// rk2_1D :367, rk4_1D :497.
-// ---------------------------------------------------------------------------
-template <int METHOD>
-__global__ void fwd_scan_1d_kernel(int P, int N, const double* __restrict__ A, const double* __restrict__ b,
-                                   const double* __restrict__ m0, const double* __restrict__ S0,
-                                   const double* __restrict__ Sigma, int sigma_stride, double dt,
-                                   double* __restrict__ m_out, double* __restrict__ S_out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const double* Ap = A + (size_t)p * N;
-    const double* bp = b + (size_t)p * N;
-    double* mo = m_out + (size_t)p * N;
-    double* So = S_out + (size_t)p * N;
-    const double Sig = Sigma[(size_t)p * sigma_stride];
-    const double h = 0.5 * dt;
-    double m = m0[p], S = S0[p];
-    mo[0] = m;
-    So[0] = S;
-    double At = Ap[0], bt = bp[0];
-    for (int t = 0; t + 1 < N; ++t) {
-        const double An = Ap[t + 1], bn = bp[t + 1];
-        if (METHOD == VGPA_EULER) {
-            const double mn = m + (-At * m + bt) * dt;
-            S = S + (-2 * At * S + Sig) * dt;
-            m = mn;
-        } else if (METHOD == VGPA_HEUN) {
-            double ftp = -At * m + bt;
-            double ftc = -An * (m + ftp * dt) + bn;
-            const double mn = m + h * (ftp + ftc);
-            ftp = -2 * At * S + Sig;
-            ftc = -2 * An * (S + ftp * dt) + Sig;
-            S = S + h * (ftp + ftc);
-            m = mn;
-        } else if (METHOD == VGPA_RK2) {
-            const double Ak = 0.5 * (At + An), bk = 0.5 * (bt + bn);
-            const double mn = m + (-Ak * (m + h * (-At * m + bt)) + bk) * dt;
-            S = S + (-2 * Ak * (S + h * (-2 * At * S + Sig)) + Sig) * dt;
-            m = mn;
-        } else {
-            const double Ak = 0.5 * (At + An), bk = 0.5 * (bt + bn);
-            const double K1 = (-At * m + bt) * dt;
-            const double K2 = (-Ak * (m + 0.5 * K1) + bk) * dt;
-            const double K3 = (-Ak * (m + 0.5 * K2) + bk) * dt;
-            const double K4 = (-An * (m + K3) + bn) * dt;
-            const double L1 = (-2 * At * S + Sig) * dt;
-            const double L2 = (-2 * Ak * (S + 0.5 * L1) + Sig) * dt;
-            const double L3 = (-2 * Ak * (S + 0.5 * L2) + Sig) * dt;
-            const double L4 = (-2 * An * (S + L3) + Sig) * dt;
-            m = m + (K1 + 2.0 * (K2 + K3) + K4) / 6.0;
-            S = S + (L1 + 2.0 * (L2 + L3) + L4) / 6.0;
-        }
-        mo[t + 1] = m;
-        So[t + 1] = S;
-        At = An;
-        bt = bn;
-    }
-}
-
-template <int METHOD>
-__global__ void bwd_scan_1d_kernel(int P, int N, const double* __restrict__ A, const double* __restrict__ dEdm,
-                                   const double* __restrict__ dEdS, const double* __restrict__ jm,
-                                   const double* __restrict__ jS_dense, const int* __restrict__ obs_flag,
-                                   const double* __restrict__ jumpS, int jumpS_stride, double dt,
-                                   const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
-                                   double* __restrict__ lam_out, double* __restrict__ Psi_out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const double* Ap = A + (size_t)p * N;
-    const double* gm = dEdm + (size_t)p * N;
-    const double* gS = dEdS + (size_t)p * N;
-    const double* jmp = jm + (size_t)p * N;
-    const double* jSd = jS_dense ? jS_dense + (size_t)p * N : nullptr;
-    const double jval = (!jSd && jumpS && obs_flag) ? jumpS[(size_t)p * jumpS_stride] : 0.0;
-    double* lo = lam_out + (size_t)p * N;
-    double* Po = Psi_out + (size_t)p * N;
-    const double h = 0.5 * dt;
-    double lam = lam_last ? lam_last[p] : 0.0, Psi = Psi_last ? Psi_last[p] : 0.0;
-    lo[N - 1] = lam;
-    Po[N - 1] = Psi;
-    double At = Ap[N - 1], gmt = gm[N - 1], gSt = gS[N - 1];
-    for (int t = N - 1; t >= 1; --t) {
-        const double Ak_ = Ap[t - 1], gmp = gm[t - 1], gSp = gS[t - 1];
-        double ln, Pn;
-        if (METHOD == VGPA_EULER) {
-            ln = lam - (-gmt + At * lam) * dt;
-            Pn = Psi - (-gSt + 2.0 * Psi * At) * dt;
-        } else if (METHOD == VGPA_HEUN) {
-            double ftp = -gmt + At * lam;
-            double ftc = -gmp + Ak_ * (lam - ftp * dt);
-            ln = lam - h * (ftp + ftc);
-            ftp = -gSt + 2.0 * Psi * At;
-            ftc = -gSp + 2.0 * (Psi - ftp * dt) * Ak_;
-            Pn = Psi - h * (ftp + ftc);
-        } else if (METHOD == VGPA_RK2) {
-            const double Ak = 0.5 * (Ak_ + At), gmk = 0.5 * (gmp + gmt), gSk = 0.5 * (gSp + gSt);
-            const double lamk = lam - h * (-gmt + At * lam);
-            ln = lam - (-gmk + Ak * lamk) * dt;
-            const double Psik = Psi - h * (-gSt + 2.0 * Psi * At);
-            Pn = Psi - (-gSk + 2.0 * Psik * Ak) * dt;
-        } else {
-            const double Ak = 0.5 * (Ak_ + At), gmk = 0.5 * (gmp + gmt), gSk = 0.5 * (gSp + gSt);
-            const double K1 = (-gmt + At * lam) * dt;
-            const double K2 = (-gmk + Ak * (lam - 0.5 * K1)) * dt;
-            const double K3 = (-gmk + Ak * (lam - 0.5 * K2)) * dt;
-            const double K4 = (-gmp + Ak_ * (lam - K3)) * dt;
-            ln = lam - (K1 + 2.0 * (K2 + K3) + K4) / 6.0;
-            const double L1 = (-gSt + 2.0 * Psi * At) * dt;
-            const double L2 = (-gSk + 2.0 * (Psi - 0.5 * L1) * Ak) * dt;
-            const double L3 = (-gSk + 2.0 * (Psi - 0.5 * L2) * Ak) * dt;
-            const double L4 = (-gSp + 2.0 * (Psi - L3) * Ak_) * dt;
-            Pn = Psi - (L1 + 2.0 * (L2 + L3) + L4) / 6.0;
-        }
-        ln += jmp[t - 1];
-        if (jSd) Pn += jSd[t - 1];
-        else if (obs_flag && obs_flag[t - 1]) Pn += jval;
-        lam = ln;
-        Psi = Pn;
-        lo[t - 1] = lam;
-        Po[t - 1] = Psi;
-        At = Ak_;
-        gmt = gmp;
-        gSt = gSp;
-    }
-}
+#include "scan_1d_prefix.h"
 
 int nd_threads(int D, bool fixed) {
     const int ntiles = ((D + TI - 1) / TI) * ((D + TJ - 1) / TJ);
@@ -1026,8 +901,9 @@ extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, c
     g_lds_refused = false;
     hipStream_t st = vgpa::as_stream(stream);
     if (D == 1) {
-        const int bs = 64, grid = (P + bs - 1) / bs;
-#define LAUNCH1(M) hipLaunchKernelGGL(fwd_scan_1d_kernel<M>, dim3(grid), dim3(bs), 0, st, P, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
+        // one workgroup per problem, the steps as a parallel prefix computation
+        const size_t lds = Prefix1D::fwd_lds_bytes();
+#define LAUNCH1(M) hipLaunchKernelGGL(fwd_scan_1d_prefix_kernel<M>, dim3(P), dim3(Prefix1D::NT), lds, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out)
         switch (method) {
             case VGPA_EULER: LAUNCH1(VGPA_EULER); break;
             case VGPA_HEUN: LAUNCH1(VGPA_HEUN); break;
@@ -1061,8 +937,8 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
     g_lds_refused = false;
     hipStream_t st = vgpa::as_stream(stream);
     if (D == 1) {
-        const int bs = 64, grid = (P + bs - 1) / bs;
-#define LAUNCH1(M) hipLaunchKernelGGL(bwd_scan_1d_kernel<M>, dim3(grid), dim3(bs), 0, st, P, N, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out)
+        const size_t lds = Prefix1D::bwd_lds_bytes();
+#define LAUNCH1(M) do { allow_lds(bwd_scan_1d_prefix_kernel<M>, lds); hipLaunchKernelGGL(bwd_scan_1d_prefix_kernel<M>, dim3(P), dim3(Prefix1D::NT), lds, st, N, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out); } while (0)
         switch (method) {
             case VGPA_EULER: LAUNCH1(VGPA_EULER); break;
             case VGPA_HEUN: LAUNCH1(VGPA_HEUN); break;
