@@ -762,7 +762,7 @@ void launch_l96_tiled_h(const EsdeArgs& a, size_t total, hipStream_t st) {
 // dimension holds are launched in slices of the problem axis.
 void launch_l96_wave40(const EsdeArgs& a, hipStream_t st) {
     constexpr int MAXP = 65535;
-    const size_t lds = sizeof(double) * L96Wave::LDS_DOUBLES;
+    const size_t lds = L96Wave::WG_LDS_BYTES;
     const size_t N = (size_t)a.N, D = 40, DD = 1600;
     for (int p0 = 0; p0 < a.P; p0 += MAXP) {
         EsdeArgs s = a;
@@ -776,9 +776,9 @@ void launch_l96_wave40(const EsdeArgs& a, hipStream_t st) {
         if (s.dth_t) s.dth_t += o * D;
         if (s.dSig_t) s.dSig_t += o * D;
         if (s.status) s.status += o;
-        const dim3 grid((unsigned)s.N, (unsigned)s.P);
-        if (s.dSig_t) hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<true>, grid, dim3(64), lds, st, s);
-        else hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<false>, grid, dim3(64), lds, st, s);
+        const dim3 grid((unsigned)((s.N + 1) / 2), (unsigned)s.P);      // two steps per workgroup
+        if (s.dSig_t) hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<true>, grid, dim3(128), lds, st, s);
+        else hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<false>, grid, dim3(128), lds, st, s);
     }
 }
 

@@ -1,8 +1,11 @@
 // Lorenz-96 unscented energy kernel for D = 40: ONE WAVEFRONT per (problem, time step),
-// eight steps in flight per CU, the matrix products on the FP64 matrix cores.
+// eight steps in flight per CU, the matrix products on the FP64 matrix cores.  Workgroups are
+// pairs of wavefronts (two consecutive steps) that share nothing but the factorisation of the
+// diagonal blocks: see wv_factor_diag.
 //
 // Everything a step needs sits in one 40 x 42 LDS matrix `buf` (plus a 16 x 16 scratch
-// tile, a few vectors and a dump area, 20 KB in all) and in registers; no block barrier.
+// tile, a few vectors and a dump area, 20 KB in all) and in registers; the only barriers are the
+// six around the three diagonal blocks.
 //
 //   buf, lower triangle:  c2 S(t) -> L' = chol(c2 S) -> W' = L'^-1, block by block in place
 //                         (c2 = D + kappa: L' = sqrt(c2) L holds the sigma-point offsets)
@@ -69,6 +72,7 @@ struct L96Wave {
     static constexpr int OFF_DUMP = OFF_VEC + 7 * VL;
     static constexpr int OFF_ZERO = OFF_DUMP + 64 + 3 * LD;        // dump >= 128: two doubles per lane as well
     static constexpr int LDS_DOUBLES = OFF_ZERO + 16;              // zeros: what a masked operand load reads
+    static constexpr size_t WG_LDS_BYTES = sizeof(double) * (2 * LDS_DOUBLES + 2);   // two steps + two flags
 };
 
 __device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
@@ -190,18 +194,27 @@ struct WvScale {
 // In: the block of the partly updated S in buf.  Out: L_JJ in the lower triangle of the
 // block; T_J = L_JJ^-1 transposed and shifted two columns right in its upper triangle.
 // Lane c of row 0 (of 16 lanes) holds column c of the block, lane c of row 1 column c of M,
-// the accumulated row operations (M = I at the start); rows 2 and 3 repeat rows 0 and 1.
+// the accumulated row operations (M = I at the start); rows 2 and 3 do the same for a second block.
 // Per pivot k every lane eliminates its column, x[i] -= t_i x[k], with the multipliers
 // t_i = S[k][i] / S[k][k] taken by DPP broadcast from lane i of the S row.  That leaves
 // U = D L~' in the S lanes and M = L~^-1 in the M lanes (S = L~ D L~'), so L = U' D^-1/2 and
 // T = D^-1/2 M: both are x[i] / sqrt(d_i).  No LDS traffic and no scalar registers inside
-// the pivot chain.  Returns false on a pivot <= 0 (a NaN pivot is not flagged: it poisons the
-// outputs of the step instead).
+// the pivot chain.  A pivot <= 0 is reported (a NaN pivot is not: it poisons the outputs of the
+// step instead).
+//
+// The two halves of the wavefront factor two different blocks: lanes 0..31 the block in `buf`, lanes
+// 32..63 the block at the same place `other` doubles further on in LDS (the buffer of the partner
+// wavefront's step; other = 0 makes both halves factor the same block).  Bit 0 of the result is
+// clear when a pivot of the first block was not positive, bit 1 for the second.
 template <int J>
-__device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, const double* zeros, int lane) {
+__device__ __forceinline__ int wv_factor_diag(double* buf0, double* dump0, const double* zeros0, int other, int lane) {
     constexpr int LD = L96Wave::LD, c0 = 16 * J, NP = (J == 2) ? 8 : 16;
     const int c = lane & 15;
     const bool is_m = (lane & 16) != 0;
+    const int shift = (lane & 32) ? other : 0;
+    double* buf = buf0 + shift;
+    double* dump = dump0 + shift;
+    const double* zeros = zeros0 + shift;
     double x[NP];
     {
         // S lanes: column c = row c (symmetric); M lanes: sixteen zeros, then the one of I
@@ -229,11 +242,11 @@ __device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, const 
     // piece, and every lane beyond the block, goes to the lane's dump slot.
     {
         const int hc = c >> 1;
-        const bool lane_writes = lane < 32 && c < NP;
+        const bool lane_writes = c < NP;                               // both halves write (equal values when other = 0)
         const unsigned first = is_m ? hc : 0;                            // pieces first .. first + count - 1
         const unsigned count = lane_writes ? (is_m ? NP / 2 - hc : hc + 1) : 0;
         double* dst = buf + (c0 + c) * LD + c0 + (is_m ? 2 : 0);
-        double* nowhere = dump + 2 * lane;
+        double* nowhere = dump + 2 * (lane & 31);
 #pragma unroll
         for (int h = 0; h < NP / 2; ++h) {
             const bool wr = (unsigned)h - first < count;
@@ -242,7 +255,8 @@ __device__ __forceinline__ bool wv_factor_diag(double* buf, double* dump, const 
     }
     wave_lds_fence();
     // every pivot is the pivc of one S lane
-    return __builtin_amdgcn_ballot_w64(!(pivc > 0.0)) == 0;
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(!(pivc > 0.0));
+    return ((bad & 0xffffffffull) == 0 ? 1 : 0) | ((bad >> 32) == 0 ? 2 : 0);
 }
 
 // indices l + 1, l - 1, l - 2 on the ring of D = 40 components
@@ -253,10 +267,17 @@ __device__ __forceinline__ void wv_ring(int l, int& f1, int& b1, int& b2) {
 }
 
 template <bool HYPER>
-__global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
+__global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     using C = L96Wave;
     constexpr int D = C::D, LD = C::LD, DD = C::DD, XLD = C::XLD, VL = C::VL;
-    extern __shared__ double lds[];
+    extern __shared__ double lds_all[];
+    // Two wavefronts, two consecutive steps, each with its own LDS image.  They only meet at the three
+    // diagonal blocks of the factorisation, which ONE of them factors for both (the halves of that
+    // wavefront take a block each) while the other waits at the barrier.
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    double* lds = lds_all + wv * C::LDS_DOUBLES;
+    const int other = wv == 0 ? C::LDS_DOUBLES : -C::LDS_DOUBLES;
+    int* pd_flags = reinterpret_cast<int*>(lds_all + 2 * C::LDS_DOUBLES);     // [w]: the blocks of wavefront w were positive definite
     double* buf = lds;
     double* Xs = lds + C::OFF_X;
     double* mv = lds + C::OFF_VEC;
@@ -268,10 +289,10 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     double* mvx = sbv + VL;     // mvx[k] = m[(k - 2) mod 40], k = 0 .. 47: stencil windows need no wrap
     double* dump = lds + C::OFF_DUMP;
     const double* zslot = lds + C::OFF_ZERO;       // holds 0.0: masked loads select this address
-    const int lane0 = threadIdx.x;
+    const int lane0 = threadIdx.x & 63;
     constexpr int NQ3 = (D + 2) / 3;               // 14 load instructions of three rows of S(t) each
     const int p = blockIdx.y;                      // problem, step: no division by N
-    const size_t e = (size_t)p * a.N + blockIdx.x;
+    const size_t e = (size_t)p * a.N + min(2 * (int)blockIdx.x + wv, a.N - 1);   // an odd last step is done twice
     // The lane index is made opaque again at every phase: addresses and masks derived from it
     // are then recomputed where they are used instead of being kept in registers (or spilled)
     // from one phase to the next.
@@ -336,6 +357,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
         basev[lane] = 0.0;
     }
     if (lane < 16) lds[C::OFF_ZERO + lane] = 0.0;
+    if (lane == 0) pd_flags[wv] = 1;
     wave_lds_fence();
 
     // the covariance term of <f>, before S is overwritten by its factor
@@ -380,7 +402,19 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q * LD] = t[q];
     };
-    bool ok = wv_factor_diag<0>(buf, dump, zslot, lane);
+    bool ok = true;
+    // diagonal block J of both steps by wavefront J & 1
+#define WV_FACTOR_BOTH(J)                                                            \
+    do {                                                                             \
+        __syncthreads();                                                             \
+        if (wv == ((J) & 1)) {                                                       \
+            const int r = wv_factor_diag<J>(buf, dump, zslot, other, lane);          \
+            ok = ok && (r & 1);                                                      \
+            if (lane == 0 && !(r & 2)) pd_flags[1 - wv] = 0;                         \
+        }                                                                            \
+        __syncthreads();                                                             \
+    } while (0)
+    WV_FACTOR_BOTH(0);
     WV_STAMP(27);
     {
         // block column 0: panel L_10, L_20 = S_I0 T_0'
@@ -420,7 +454,7 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     }
     WV_STAMP(28);
     WV_RELANE();
-    ok = wv_factor_diag<1>(buf, dump, zslot, lane) && ok;
+    WV_FACTOR_BOTH(1);
     WV_STAMP(29);
     {
         // block column 1: panel L_21 = S_21 T_1'
@@ -455,7 +489,9 @@ __global__ void __launch_bounds__(64, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     }
     WV_STAMP(30);
     WV_RELANE();
-    ok = wv_factor_diag<2>(buf, dump, zslot, lane) && ok;
+    WV_FACTOR_BOTH(2);
+#undef WV_FACTOR_BOTH
+    ok = ok && __builtin_amdgcn_readfirstlane(pd_flags[wv]) != 0;
 
     WV_STAMP(18);
     WV_RELANE();
