@@ -3,9 +3,9 @@
 // pairs of wavefronts (two consecutive steps) that share nothing but the factorisation of the
 // diagonal blocks: see wv_factor_diag.
 //
-// Everything a step needs sits in one 40 x 42 LDS matrix `buf` (plus a 16 x 16 scratch
-// tile, a few vectors and a dump area, 20 KB in all) and in registers; the only barriers are the
-// six around the three diagonal blocks.
+// Everything a step needs sits in one 40 x 42 LDS matrix `buf` (its dead corners are the scratch)
+// plus a few vectors, 16.3 KB in all, and in registers; the only barriers are the six around the
+// three diagonal blocks.
 //
 //   buf, lower triangle:  c2 S(t) -> L' = chol(c2 S) -> W' = L'^-1, block by block in place
 //                         (c2 = D + kappa: L' = sqrt(c2) L holds the sigma-point offsets)
@@ -63,16 +63,23 @@ typedef double wv_f64x4 __attribute__((ext_vector_type(4)));
 
 struct L96Wave {
     static constexpr int D = 40, LD = 42, MS = D * LD, DD = D * D;
-    static constexpr int XLD = 18;                       // scratch tile
-    static constexpr int OFF_X = MS;
-    static constexpr int OFF_VEC = OFF_X + 16 * XLD;
+    // The blocks of `buf` above the diagonal blocks are dead once S(t) is loaded (only the lower blocks
+    // and the full diagonal blocks are read, and T_J shifted two columns reaches column 16 J + 17).
+    // They hold the scratch:
+    //   rows 0..15, columns 18..33   the 16 x 16 transposition tile of the inversion
+    //   rows 0..31, columns 34..41   where stores of lanes whose row or column does not exist go (an
+    //                                address select instead of an exec-mask region); lanes may share
+    //                                a slot, nobody reads them
+    static constexpr int X_COL = 18, DUMP_COL = 34;
+    static constexpr int OFF_VEC = MS;
     static constexpr int VL = 48;                        // vectors: m, A m - b, Sigma^-1, u, sa, sb, m on the ring
-    // Stores of lanes whose row or column does not exist go to a per-lane slot here (an
-    // address select instead of an exec-mask region); a slot takes the four rows of a tile.
-    static constexpr int OFF_DUMP = OFF_VEC + 7 * VL;
-    static constexpr int OFF_ZERO = OFF_DUMP + 64 + 3 * LD;        // dump >= 128: two doubles per lane as well
-    static constexpr int LDS_DOUBLES = OFF_ZERO + 16;              // zeros: what a masked operand load reads
+    static constexpr int OFF_ZERO = OFF_VEC + 7 * VL;    // zeros: what a masked operand load reads
+    static constexpr int LDS_DOUBLES = OFF_ZERO + 16;
     static constexpr size_t WG_LDS_BYTES = sizeof(double) * (2 * LDS_DOUBLES + 2);   // two steps + two flags
+    // dump slots: four rows LD apart from the first / two doubles / four doubles per lane
+    static __device__ __forceinline__ int dump_rows4(int lane) { return (lane >> 3) * LD + DUMP_COL + (lane & 7); }
+    static __device__ __forceinline__ int dump_pair(int lane) { return ((lane & 31) >> 2) * LD + DUMP_COL + 2 * (lane & 3); }
+    static __device__ __forceinline__ int dump_quad(int lane) { return (lane >> 1) * LD + DUMP_COL + 4 * (lane & 1); }
 };
 
 __device__ __forceinline__ wv_f64x4 wv_mfma(double a, double b, wv_f64x4 c) {
@@ -207,13 +214,12 @@ struct WvScale {
 // wavefront's step; other = 0 makes both halves factor the same block).  Bit 0 of the result is
 // clear when a pivot of the first block was not positive, bit 1 for the second.
 template <int J>
-__device__ __forceinline__ int wv_factor_diag(double* buf0, double* dump0, const double* zeros0, int other, int lane) {
+__device__ __forceinline__ int wv_factor_diag(double* buf0, const double* zeros0, int other, int lane) {
     constexpr int LD = L96Wave::LD, c0 = 16 * J, NP = (J == 2) ? 8 : 16;
     const int c = lane & 15;
     const bool is_m = (lane & 16) != 0;
     const int shift = (lane & 32) ? other : 0;
     double* buf = buf0 + shift;
-    double* dump = dump0 + shift;
     const double* zeros = zeros0 + shift;
     double x[NP];
     {
@@ -246,7 +252,7 @@ __device__ __forceinline__ int wv_factor_diag(double* buf0, double* dump0, const
         const unsigned first = is_m ? hc : 0;                            // pieces first .. first + count - 1
         const unsigned count = lane_writes ? (is_m ? NP / 2 - hc : hc + 1) : 0;
         double* dst = buf + (c0 + c) * LD + c0 + (is_m ? 2 : 0);
-        double* nowhere = dump + 2 * (lane & 31);
+        double* nowhere = buf + L96Wave::dump_pair(lane);
 #pragma unroll
         for (int h = 0; h < NP / 2; ++h) {
             const bool wr = (unsigned)h - first < count;
@@ -269,7 +275,7 @@ __device__ __forceinline__ void wv_ring(int l, int& f1, int& b1, int& b2) {
 template <bool HYPER>
 __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     using C = L96Wave;
-    constexpr int D = C::D, LD = C::LD, DD = C::DD, XLD = C::XLD, VL = C::VL;
+    constexpr int D = C::D, LD = C::LD, DD = C::DD, VL = C::VL;
     extern __shared__ double lds_all[];
     // Two wavefronts, two consecutive steps, each with its own LDS image.  They only meet at the three
     // diagonal blocks of the factorisation, which ONE of them factors for both (the halves of that
@@ -279,7 +285,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     const int other = wv == 0 ? C::LDS_DOUBLES : -C::LDS_DOUBLES;
     int* pd_flags = reinterpret_cast<int*>(lds_all + 2 * C::LDS_DOUBLES);     // [w]: the blocks of wavefront w were positive definite
     double* buf = lds;
-    double* Xs = lds + C::OFF_X;
+    double* Xs = buf + C::X_COL;
     double* mv = lds + C::OFF_VEC;
     double* basev = mv + VL;
     double* sIv = basev + VL;
@@ -287,7 +293,6 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     double* sav = uv + VL;      // sqrt|g|
     double* sbv = sav + VL;     // sign(g) sqrt|g|
     double* mvx = sbv + VL;     // mvx[k] = m[(k - 2) mod 40], k = 0 .. 47: stencil windows need no wrap
-    double* dump = lds + C::OFF_DUMP;
     const double* zslot = lds + C::OFF_ZERO;       // holds 0.0: masked loads select this address
     const int lane0 = threadIdx.x & 63;
     constexpr int NQ3 = (D + 2) / 3;               // 14 load instructions of three rows of S(t) each
@@ -395,7 +400,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     // in block row / column 2) write to their dump slot
     auto tile_ptr = [&](int I, int K) {
         const bool valid = (I < 2 || g4 < 2) && (K < 2 || c16 < 8);
-        return valid ? buf + (16 * I + 4 * g4) * LD + 16 * K + c16 : dump + lane;
+        return buf + (valid ? (16 * I + 4 * g4) * LD + 16 * K + c16 : C::dump_rows4(lane));
     };
     auto tile_wr = [&](int I, int K, const wv_f64x4& t) {
         double* dst = tile_ptr(I, K);
@@ -408,7 +413,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     do {                                                                             \
         __syncthreads();                                                             \
         if (wv == ((J) & 1)) {                                                       \
-            const int r = wv_factor_diag<J>(buf, dump, zslot, other, lane);          \
+            const int r = wv_factor_diag<J>(buf, zslot, other, lane);                \
             ok = ok && (r & 1);                                                      \
             if (lane == 0 && !(r & 2)) pd_flags[1 - wv] = 0;                         \
         }                                                                            \
@@ -728,11 +733,11 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
         };
         auto xs_wr = [&](const wv_f64x4& t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Xs[(4 * g4 + q) * XLD + c16] = t[q];
+            for (int q = 0; q < 4; ++q) Xs[(4 * g4 + q) * LD + c16] = t[q];
         };
         auto xs_rd = [&](double (&o)[4]) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) o[s] = Xs[(4 * s + g4) * XLD + c16];
+            for (int s = 0; s < 4; ++s) o[s] = Xs[(4 * s + g4) * LD + c16];
         };
         const wv_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
         double t0[4], t1[4], l10[4], l20[4], l21[4], nt1[4], nt2[4];
@@ -802,7 +807,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             *reinterpret_cast<double2*>(dst + 2) = make_double2(t[J][2], t[J][3]);
         }
         {
-            double* dst = (ra < 8 && cb < 8) ? buf + (32 + ra) * LD + 32 + cb : dump + 2 * lane;
+            double* dst = buf + ((ra < 8 && cb < 8) ? (32 + ra) * LD + 32 + cb : C::dump_quad(lane));
             *reinterpret_cast<double2*>(dst) = make_double2(t[2][0], t[2][1]);
             *reinterpret_cast<double2*>(dst + 2) = make_double2(t[2][2], t[2][3]);
         }
