@@ -2,7 +2,7 @@
 // same SIMD?  A 512-thread workgroup puts wavefronts w and w + 4 on one SIMD.  Wavefronts 0..3
 // run role A, wavefronts 4..7 role B; each role is timed alone and together with the other.
 //   roles: 0 idle, 1 v_mfma_f64_16x16x4_f64 (4 accumulators), 2 v_fma_f64 (16 chains),
-//          3 32-bit integer v_mad (16 chains), 4 v_fma_f32 (16 chains)
+//          3 32-bit integer v_mad (16 chains), 4 v_fma_f32 (16 chains), 5 v_mfma_f64 on one accumulator
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -17,6 +17,14 @@ __device__ __forceinline__ long long run_role(int iters, double* sink, int tid) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) c[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[k], 0, 0, 0);
         if (c[0][0] + c[1][1] + c[2][2] + c[3][3] == 12345.0) sink[0] = 1.0;
+    } else if (ROLE == 5) {
+        // one accumulator: every instruction depends on the previous one
+        f64x4 c = {0, 0, 0, 0};
+        const double a = 1.0 + tid, b = 0.5;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        if (c[0] + c[1] == 12345.0) sink[0] = 1.0;
     } else if (ROLE == 2) {
         double x[16];
 #pragma unroll
@@ -90,5 +98,7 @@ int main() {
     go<1, 4>("mfma f64 + fma f32", it, 4, 16);
     go<2, 2>("fma f64 + fma f64", it, 16, 16);
     go<1, 1>("mfma f64 + mfma f64", it, 4, 4);
+    go<5, 0>("mfma f64, one accumulator", it, 4, 0);
+    go<5, 2>("mfma f64 (one acc.) + fma f64", it, 4, 16);
     return 0;
 }
