@@ -769,18 +769,27 @@ fwd_scan_small_rows_kernel(int P, int N, const double* __restrict__ A, const dou
         double* myS = lds + 2 * IN + (c & 1) * OUT + pl * OutS::STRIDE + i * D;
         double* mym = lds + 2 * IN + (c & 1) * OUT + OutS::LDS + pl * Outm::STRIDE + i;
         __syncthreads();
+        // The inputs of step u + 1 are read from LDS before the state of row u is stored there: the
+        // compiler cannot move a load above a store that might alias, and a load issued only after the
+        // store would put its latency on the chain of every step.
+        double At[2][DD], ai[2][D], bi[2];
+        auto load_in = [&](int u, int w) {
+            Tm::load(myA + u * DD, At[w]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) ai[w][k] = myA[u * DD + i * D + k];
+            bi[w] = myb[u * D];
+        };
+        load_in(0, 0);
 #pragma unroll
         for (int u = 0; u < T; ++u) {
+            const int w = u & 1;
+            if (u + 1 < T) load_in(u + 1, w ^ 1);
             // row T c + u is the current state; then one step with row u of the chunk
 #pragma unroll
             for (int j = 0; j < D; ++j) myS[u * DD + j] = Sr[j];
             mym[u * D] = mi;
-            double S[DD], m[D], At[DD], ai[D];
+            double S[DD], m[D];
             QuadGather<D, 0>::run(Sr, mi, S, m);
-            Tm::load(myA + u * DD, At);
-#pragma unroll
-            for (int k = 0; k < D; ++k) ai[k] = myA[u * DD + i * D + k];
-            const double bi = myb[u * D];
             // row i of  S + dt (Sig - A S - S A')  and entry i of  m + dt (-A m + b)   (core/fwd_ode.py:121-131)
             double Sn[D];
 #pragma unroll
@@ -788,16 +797,16 @@ fwd_scan_small_rows_kernel(int P, int N, const double* __restrict__ A, const dou
                 double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    s1 = fma(ai[k], S[k * D + j], s1);
-                    s2 = fma(Sr[k], At[j * D + k], s2);
+                    s1 = fma(ai[w][k], S[k * D + j], s1);
+                    s2 = fma(Sr[k], At[w][j * D + k], s2);
                 }
                 const double K = -s1 - s2 + Sgr[j];
                 Sn[j] = Sr[j] + dt * K;
             }
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) s = fma(ai[k], m[k], s);
-            const double f = -s + bi;
+            for (int k = 0; k < D; ++k) s = fma(ai[w][k], m[k], s);
+            const double f = -s + bi[w];
             mi = mi + dt * f;
 #pragma unroll
             for (int j = 0; j < D; ++j) Sr[j] = Sn[j];
@@ -905,48 +914,56 @@ bwd_scan_small_rows_kernel(int P, int N, const double* __restrict__ A, const dou
         double* myl = lds + 2 * IN + (v & 1) * OUT + OutM::LDS + pl * Outv::STRIDE + i;
         const int t0 = T * (nch - 1 - v);
         __syncthreads();
+        // inputs of the next step are read before the current row is stored (see the forward kernel)
+        double At[2][DD], ari[2][D], aci[2][D], Gi[2][D], gi[2], jvi[2];
+        bool on[2];
+        auto load_in = [&](int u, int w) {
+            // chunk rows: row t = t0 + u is entry u + 2, row t - 1 entry u + 1
+            Tm::load(myA + (u + 2) * DD, At[w]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                ari[w][k] = myA[(u + 2) * DD + i * D + k];
+                aci[w][k] = myA[(u + 2) * DD + k * D + i];
+                Gi[w][k] = myG[(u + 2) * DD + k];
+            }
+            gi[w] = myg[(u + 2) * D];
+            jvi[w] = myj[(u + 1) * D];
+            on[w] = flagged && t0 + u >= 1 && t0 + u < N && obs_flag[t0 + u - 1] != 0;      // core/bwd_ode.py:124,127
+        };
+        load_in(T - 1, (T - 1) & 1);
 #pragma unroll
         for (int u = T - 1; u >= 0; --u) {
             const int t = t0 + u;
+            const int w = u & 1;
+            if (u >= 1) load_in(u - 1, w ^ 1);
             if (t < N) {                              // uniform: only the top chunk has rows beyond N - 1
 #pragma unroll
                 for (int j = 0; j < D; ++j) myP[u * DD + j] = Xr[j];
                 myl[u * D] = xi;
                 if (t >= 1) {
-                    // chunk rows: row t is entry u + 2, row t - 1 entry u + 1
-                    double X[DD], x[D], At[DD], ari[D], aci[D], Gi[D];
+                    double X[DD], x[D];
                     QuadGather<D, 0>::run(Xr, xi, X, x);
-                    Tm::load(myA + (u + 2) * DD, At);
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        ari[k] = myA[(u + 2) * DD + i * D + k];
-                        aci[k] = myA[(u + 2) * DD + k * D + i];
-                        Gi[k] = myG[(u + 2) * DD + k];
-                    }
-                    const double gi = myg[(u + 2) * D];
-                    const double jvi = myj[(u + 1) * D];
                     // row i of  Psi - dt (-G + Psi A + A' Psi)  and entry i of  lam - dt (-g + A lam)   (core/bwd_ode.py:117-127)
                     const double ndt = -dt;
-                    const bool on = flagged && obs_flag[t - 1] != 0;
                     double Xn[D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
                         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
-                            s1 = fma(Xr[k], At[k * D + j], s1);
-                            s2 = fma(aci[k], X[k * D + j], s2);
+                            s1 = fma(Xr[k], At[w][k * D + j], s1);
+                            s2 = fma(aci[w][k], X[k * D + j], s2);
                         }
-                        const double K = -Gi[j] + (s1 + s2);
+                        const double K = -Gi[w][j] + (s1 + s2);
                         Xn[j] = Xr[j] + ndt * K;
-                        Xn[j] += on ? jtr[j] : 0.0;
+                        Xn[j] += on[w] ? jtr[j] : 0.0;
                     }
                     double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) s = fma(ari[k], x[k], s);
-                    const double f = -gi + s;
+                    for (int k = 0; k < D; ++k) s = fma(ari[w][k], x[k], s);
+                    const double f = -gi[w] + s;
                     xi = xi + ndt * f;
-                    xi += jvi;
+                    xi += jvi[w];
 #pragma unroll
                     for (int j = 0; j < D; ++j) Xr[j] = Xn[j];
                 }
