@@ -559,6 +559,36 @@ def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer
     return st, gLA, gLb
 
 
+class CapturedEvaluation:
+    """One free-energy + gradient evaluation recorded as a HIP graph.
+
+    For small problems (a single 1-D or Lorenz-63 smoothing run) the dozen kernel launches and the
+    tensor bookkeeping around them cost more than the kernels; replaying a graph issues them with
+    one call.  ``A`` and ``b`` are the buffers the graph reads: write new parameter values INTO them
+    (``A.copy_(...)``) and call ``replay()``; ``state``, ``gLA``, ``gLb`` are the buffers it writes,
+    the same objects after every replay.  Everything the evaluation allocates comes from the graph's
+    private pool, so nothing is allocated at replay.  The per-step status is not checked here: call
+    ``check_status(self.state.status)`` when a result is consumed.
+    """
+
+    def __init__(self, prob, A, b, want_hyper=False, outer=False):
+        if prob.system < 0:
+            raise ValueError("a host plug-in energy function cannot be captured")
+        self.prob, self.A, self.b = prob, A, b
+        kl0(prob)                                        # cached on the problem: outside the graph
+        # one eager run first: lazy initialisation (kernel attributes, library handles) must not
+        # happen inside a capture
+        free_energy_and_gradient(prob, A, b, want_hyper=want_hyper, outer=outer)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.state, self.gLA, self.gLb = free_energy_and_gradient(prob, A, b, want_hyper=want_hyper, outer=outer)
+
+    def replay(self):
+        self.graph.replay()
+        return self.state, self.gLA, self.gLb
+
+
 def check_status(status):
     """Raise like the reference when a covariance lost positive definiteness
     (auxiliary/numerical.py:199-202 lets LinAlgError escape when the diagonal
