@@ -443,8 +443,8 @@ def test_symmetric_scan_kernels_are_bitwise_the_general_ones(D, method):
     d = engine.to_dev
     m1, S1 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=True)
     m2, S2 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=False)
-    if method == "EULER" and D == 40:
-        # this case runs on the matrix cores: another summation order, so equal to rounding
+    if D == 40:
+        # this size runs on the matrix cores: another summation order, so equal to rounding
         # only, but still exactly symmetric
         assert relerr(S1.cpu().numpy(), S2.cpu().numpy()) <= 1e-13 and relerr(m1.cpu().numpy(), m2.cpu().numpy()) <= 1e-13
         assert torch.equal(S1, S1.transpose(-1, -2))
@@ -460,10 +460,11 @@ def test_symmetric_scan_kernels_are_bitwise_the_general_ones(D, method):
         assert relerr(P1[p].cpu().numpy(), Pr) <= TOL and relerr(l1[p].cpu().numpy(), lr) <= TOL
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 18])
-def test_matrix_core_euler_scans_vs_oracle(N):
-    """D = 40, Euler, symmetric state: the scans that run on the FP64 matrix cores, with
-    flagged observation jumps and a terminal state, at the shortest lengths too."""
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 18])
+def test_matrix_core_scans_vs_oracle(N, method):
+    """D = 40, symmetric state: the scans that run on the FP64 matrix cores, with flagged
+    observation jumps and a terminal state, at the shortest lengths too."""
     import torch
     from vgpa_amd import engine
     rng = np.random.default_rng(900 + N)
@@ -480,16 +481,21 @@ def test_matrix_core_euler_scans_vs_oracle(N):
     jump = sym(rng.standard_normal((D, D)))
     lamT, PsiT = rng.standard_normal((P, D)), sym(rng.standard_normal((P, D, D)))
     d = engine.to_dev
-    mid = engine.method_id("EULER")
+    mid = engine.method_id(method)
+    fl = torch.from_numpy(flag).to(engine.to_dev(m0).device)
     m1, S1 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=True)
-    l1, P1 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, obs_flag=torch.from_numpy(flag).to(m1.device),
-                             jumpS=d(jump), symmetric=True, lam_last=d(lamT), Psi_last=d(PsiT))
+    l1, P1 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, obs_flag=fl, jumpS=d(jump), symmetric=True,
+                             lam_last=d(lamT), Psi_last=d(PsiT))
     assert torch.equal(S1, S1.transpose(-1, -2)) and torch.equal(P1, P1.transpose(-1, -2))
+    # the general two-product kernels on the same inputs: equal to rounding
+    l2, P2 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, obs_flag=fl, jumpS=d(jump), symmetric=False,
+                             lam_last=d(lamT), Psi_last=d(PsiT))
+    assert relerr(P1.cpu().numpy(), P2.cpu().numpy()) <= 1e-13 and relerr(l1.cpu().numpy(), l2.cpu().numpy()) <= 1e-13
     jS = flag[:, None, None] * jump[None]
     for p in range(P):
-        mr, Sr = orc.fwd_scan(A[p], b[p], m0[p], S0[p], Sig, dt, "EULER")
+        mr, Sr = orc.fwd_scan(A[p], b[p], m0[p], S0[p], Sig, dt, method)
         assert relerr(S1[p].cpu().numpy(), Sr) <= TOL and relerr(m1[p].cpu().numpy(), mr) <= TOL
-        lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS, dt, "EULER", lam_last=lamT[p], Psi_last=PsiT[p])
+        lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS, dt, method, lam_last=lamT[p], Psi_last=PsiT[p])
         assert relerr(P1[p].cpu().numpy(), Pr) <= TOL and relerr(l1[p].cpu().numpy(), lr) <= TOL
 
 

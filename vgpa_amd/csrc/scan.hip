@@ -21,6 +21,8 @@
 //        Psi A + A' Psi = Q + Q' with Q = Psi A: one product per stage instead of
 //        two, the transpose going through LDS.  Because the same products are
 //        summed in the same order, the result is bit-for-bit the general one.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -767,6 +769,7 @@ void allow_lds(K kernel, size_t bytes) {
 }
 
 #include "scan_mfma.h"
+#include "scan_mfma_stages.h"
 #include "scan_fused.h"
 #define VGPA_SMALL_D_SCANS
 #include "small_d.h"
@@ -837,6 +840,13 @@ void launch_fwd(int P, int N, int D, const double* A, const double* b, const dou
                            sigma_stride, dt, m_out, S_out);
         return;
     }
+    if constexpr (METHOD != VGPA_EULER && DT == 40 && SYM) {
+        const size_t lds = sizeof(double) * M40S<METHOD>::LDS_DOUBLES;
+        allow_lds(fwd_stages_sym_mfma40_kernel<METHOD>, lds);
+        hipLaunchKernelGGL(fwd_stages_sym_mfma40_kernel<METHOD>, dim3(P), dim3(M40::NT), lds, st, N, A, b, m0, S0, Sigma,
+                           sigma_stride, dt, m_out, S_out);
+        return;
+    }
     const size_t lds = nd_lds_bytes(D, DT > 0, METHOD, SYM);
     allow_lds(fwd_scan_nd_kernel<METHOD, DT, SYM>, lds);
     hipLaunchKernelGGL((fwd_scan_nd_kernel<METHOD, DT, SYM>), dim3(P), dim3(nd_threads(D, DT > 0)), lds, st, N, D, A, b, m0,
@@ -856,6 +866,15 @@ void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const 
             const size_t lds = sizeof(double) * (M40::LDS_DOUBLES + M40::MS);
             allow_lds(bwd_euler_sym_mfma40_kernel, lds);
             hipLaunchKernelGGL(bwd_euler_sym_mfma40_kernel, dim3(P), dim3(M40::NT), lds, st, N, A, dEdm, dEdS, jm,
+                               obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+            return;
+        }
+    }
+    if constexpr (METHOD != VGPA_EULER && DT == 40 && SYM) {
+        if (!jS) {
+            const size_t lds = sizeof(double) * M40S<METHOD>::LDS_DOUBLES;
+            allow_lds(bwd_stages_sym_mfma40_kernel<METHOD>, lds);
+            hipLaunchKernelGGL(bwd_stages_sym_mfma40_kernel<METHOD>, dim3(P), dim3(M40::NT), lds, st, N, A, dEdm, dEdS, jm,
                                obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
             return;
         }
