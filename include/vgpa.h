@@ -68,7 +68,10 @@ extern "C" {
                                     inputs (forward: S0 and Sigma; backward: every
                                     dEsde_dS[t] and every jump).  The scan then forms
                                     one matrix product per stage instead of two; the
-                                    result is bit-for-bit that of the general path. */
+                                    result is bit-for-bit that of the general path,
+                                    except at D = 40, where that product runs on the FP64
+                                    matrix cores in another summation order: equal to
+                                    rounding, and still exactly symmetric. */
 
 #define VGPA_SCAN_STATE_SYMMETRIC 2  /* vgpa_bwd_scan_grad only: every S[t] is bitwise symmetric too
                                        (it is when it came from vgpa_fwd_scan with

@@ -20,7 +20,9 @@
 //        the jumps).  Then -A S - S A' = -(M + M') with M = A S, and
 //        Psi A + A' Psi = Q + Q' with Q = Psi A: one product per stage instead of
 //        two, the transpose going through LDS.  Because the same products are
-//        summed in the same order, the result is bit-for-bit the general one.
+//        summed in the same order, the result is bit-for-bit the general one
+//        (not at D = 40: scan_mfma.h and scan_mfma_stages.h do that product on the
+//        matrix cores, in another summation order).
 #include <type_traits>
 
 #include "common.h"
