@@ -17,11 +17,14 @@ As = [A[i * Pc:(i + 1) * Pc] for i in range(nchunk)]
 bs = [b[i * Pc:(i + 1) * Pc] for i in range(nchunk)]
 streams = [torch.cuda.Stream() for _ in range(nchunk)]
 
-def one(i):
-    st = engine.free_energy(probs[i], As[i], bs[i], want_edf=False)
-    return engine.gradient(probs[i], As[i], bs[i], st)
+whole = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
 
-def run(parallel):
+def one(i):
+    return engine.free_energy_and_gradient(probs[i], As[i], bs[i])
+
+def run(parallel, delay_ms=0.0):
+    """delay_ms: chunk i starts i * delay_ms late on its stream (a spinning one-lane kernel), so that
+    the kernels of different chunks that meet on the chip are of different kinds."""
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
@@ -29,11 +32,22 @@ def run(parallel):
         for i in range(nchunk):
             if parallel:
                 with torch.cuda.stream(streams[i]):
+                    if delay_ms and i:
+                        torch.cuda._sleep(int(i * delay_ms * 2.4e6))   # cycles at about 2.4 GHz
                     outs.append(one(i))
             else:
                 outs.append(one(i))
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / 3 * 1e3
 
-run(False); run(True)
-print(f"P={P} in {nchunk} chunks: sequential {run(False):.2f} ms, on {nchunk} streams {run(True):.2f} ms")
+def run_whole():
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = engine.free_energy_and_gradient(whole, A, b)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 3 * 1e3
+
+run(False); run(True); run_whole()
+print(f"P={P}: one call {run_whole():.2f} ms; in {nchunk} chunks: one after the other {run(False):.2f} ms, on {nchunk} streams {run(True):.2f} ms, "
+      + ", ".join(f"chunk i delayed by {d} i ms {run(True, d):.2f} ms" for d in (2.0, 4.0, 6.0)))
