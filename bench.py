@@ -296,7 +296,6 @@ def main():
             kernel_ms = {k: float(np.mean([a.elapsed_time(b_) for a, b_ in v])) for k, v in events.items()}
             esde_ms = kernel_ms["esde"]
             bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
-            achieved = units_per_launch * bytes_per_unit / (esde_ms * 1e-3) / 1e9
             # Algorithmic bytes per (problem, time step) of the other kernels: forward scan reads A, b
             # and writes m, S; the fused backward scan + gradient kernel reads A, dEsde_dS, S and five
             # vectors (dEsde_dm, jumps, m, <f>, b) and writes Psi, dL/dA, lam, dL/db.
@@ -306,26 +305,29 @@ def main():
                            "achieved_GBps": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9,
                            "frac": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                        for k in kernel_ms}
-            traffic_unit = measured_traffic_per_unit(ESDE_KERNEL)
-            line["roofline"] = {"kernel": ESDE_KERNEL, "bound": "hbm", "achieved": achieved,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                "traffic": None if traffic_unit is None else traffic_unit * units_per_launch,
-                                "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if traffic_unit is not None else None,
-                                "bytes_per_unit": bytes_per_unit, "avg_ms": esde_ms}
-            # The energy kernel against the other roof: about 170 kflop of FP64 arithmetic per unit
+            def roof(k):
+                """The roofline object of kernel k: algorithmic bytes per launch over its measured
+                average duration, and the HBM traffic the counters of the tracked profile give."""
+                t = measured_traffic_per_unit(KERNEL_NAMES[k])
+                return {"kernel": KERNEL_NAMES[k], "bound": "hbm", "achieved": kernels[k]["achieved_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[k]["frac"],
+                        "traffic": None if t is None else t * units_per_launch,
+                        "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if t is not None else None,
+                        "bytes_per_unit": per_unit[k], "avg_ms": kernels[k]["avg_ms"],
+                        "share_of_step": kernels[k]["avg_ms"] / sum(v["avg_ms"] for v in kernels.values())}
+
+            # `roofline`: the kernel with the largest share of the step (the fused backward scan +
+            # gradient since the fusion); `roofline_energy_kernel`: the expected-energy kernel, the
+            # second largest, also against the FP64 roof: about 170 kflop of arithmetic per unit
             # (factorisation D^3/3, A L' D^3, inverse D^3/3, W' diag(g) W D^3/3, 20 flop for each of the
             # D^2 sigma-point residual entries) against the 78.6 TFLOP/s FP64 peak.
+            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+            line["roofline"] = roof(dom)
+            line["roofline_energy_kernel"] = roof("esde")
             flops_per_unit = 170e3
             tf = units_per_launch * flops_per_unit / (esde_ms * 1e-3) / 1e12
-            line["roofline"]["fp64"] = {"flops_per_unit": flops_per_unit, "achieved_TFLOPs": tf, "peak": FP64_PEAK_TFLOPS,
-                                        "frac": tf / FP64_PEAK_TFLOPS}
-            # the kernel with the largest share of the step
-            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-            dom_traffic = measured_traffic_per_unit(KERNEL_NAMES[dom])
-            line["roofline_dominant"] = {"kernel": KERNEL_NAMES[dom], "bound": "hbm", "achieved": kernels[dom]["achieved_GBps"],
-                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
-                                         "traffic": None if dom_traffic is None else dom_traffic * units_per_launch,
-                                         "bytes_per_unit": per_unit[dom], "avg_ms": kernels[dom]["avg_ms"]}
+            line["roofline_energy_kernel"]["fp64"] = {"flops_per_unit": flops_per_unit, "achieved_TFLOPs": tf,
+                                                      "peak": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS}
             line["kernels"] = kernels
         else:
             line["config"] = {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
