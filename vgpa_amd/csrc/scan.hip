@@ -1021,6 +1021,6 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
 
 #ifdef VGPA_STAMPS
 extern "C" int vgpa_debug_m40_stamps(unsigned long long* out16) {
-    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_m40_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_m40_stamps), 128 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

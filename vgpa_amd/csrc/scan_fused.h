@@ -189,6 +189,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
 #pragma unroll 1
         for (int t = N - 1; t >= 0; --t) {
             __syncthreads();                   // Psi[t], A[t]', dEsde_dS[t] are in LDS
+            M40F_STAMP(0);
             mfma_f64x4 acc[3];
             double Gt[3][4];
             bool on = false;
@@ -205,7 +206,9 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                     Gt[c][reg] = Gb[L.l[c][reg]];
                 }
             }
+            M40F_STAMP(1);
             __syncthreads();                   // Psi A complete; the LDS inputs are no longer read
+            M40F_STAMP(2);
             if (t >= 1) {
                 asm volatile("" : "+v"(lane_o));
                 const M40Lane L(wid, lane_o);
@@ -218,6 +221,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                     Pb[L.l[c][reg]] = sn;
                 }
             }
+            M40F_STAMP(3);
         }
     } else if (wid == 3) {
         // ---- memory wavefront of the recurrence: A' in, lam, Psi(t) out ------------------------
@@ -236,6 +240,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
 #pragma unroll 1
         for (int t = N - 1; t >= 0; --t) {
             __syncthreads();                   // Psi[t], A[t]', lam[t] are in LDS
+            M40F_STAMP(0);
             if (t < N - 1) M40Rows::write_out(Pb, lane, Po + (size_t)t * DD);
             double lnew = 0.0;
             if (t >= 1 && lane < D) {
@@ -249,17 +254,21 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                 lnew = lv - f1 * dt + jnext;                            // core/bwd_ode.py:121-124
                 lo[(size_t)(t - 1) * D + lane] = lnew;
             }
+            M40F_STAMP(1);
             __syncthreads();                   // Psi[t], A[t]', dEsde_dS[t], lam[t] no longer read
+            M40F_STAMP(2);
             if (t >= 1) {
                 if (lane < D) lamv[lane] = lnew;
                 lv = lnew;
                 gmt = gnext;
                 M40Rows::commit<true>(preA, lane, At);
+                M40F_STAMP(4);
                 const int tp = (t >= 2) ? t - 2 : 0;
                 M40Rows::fetch(Ap + (size_t)tp * DD, lane, preA);
                 gnext = gm[(size_t)tp * D + vl];
                 jnext = jmp[(size_t)tp * D + vl];
             }
+            M40F_STAMP(3);
         }
     } else if (wid < 7) {
         // ---- gradient wavefronts: tile row r of X S -------------------------------------------
@@ -275,6 +284,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
 #pragma unroll 1
         for (int t = N - 1; t >= 0; --t) {
             __syncthreads();                   // row t: A', Psi, S, m are in LDS
+            M40F_STAMP(0);
             double x[10];
             mfma_f64x4 z[3];
             {
@@ -312,9 +322,12 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                     for (int k = 0; k < 10; ++k) z[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[k], sb[k], z[c], 0, 0, 0);
                 }
             }
+            M40F_STAMP(1);
             __syncthreads();                   // the LDS images of row t are no longer read; s1 + s2 is in LDS
+            M40F_STAMP(2);
             if (t >= 1) {
                 M40Third::commit(preS, r, lane, Sb);
+                M40F_STAMP(4);
                 M40Third::fetch(Sp + (size_t)(t >= 2 ? t - 2 : 0) * DD, r, lane, preS);
             }
             const double s12 = sc[0];
@@ -326,6 +339,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) out[L.g[c][reg]] = dt * (z[c][reg] - s12);   // core/gradL_Ab.py:170, :176
+            M40F_STAMP(3);
         }
     } else {
         // ---- second memory wavefront: dEsde_dS, m, <f>, b in; dL/db and s1 + s2 -------------------
@@ -340,6 +354,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
 #pragma unroll 1
         for (int t = N - 1; t >= 0; --t) {
             __syncthreads();                   // row t: A', lam, m are in LDS
+            M40F_STAMP(0);
             {
                 double s12 = 0.0;
                 if (lane < D) {
@@ -359,10 +374,14 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                 for (int off = 32; off >= 1; off >>= 1) s12 += __shfl_xor(s12, off, 64);
                 if (lane == 0) sc[0] = s12;
             }
+            M40F_STAMP(1);
             __syncthreads();                   // S[t], m[t] no longer read
+            M40F_STAMP(2);
             if (t >= 1) {
                 M40Rows::commit<false>(preG, lane, Gb);
+                M40F_STAMP(4);
                 if (lane < 48) mx[lane] = m_nxt;
+                M40F_STAMP(5);
                 ef_cur = ef_nxt;
                 b_cur = b_nxt;
                 const int tp = (t >= 2) ? t - 2 : 0;
@@ -371,6 +390,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                 b_nxt = bp[(size_t)tp * D + vl];
                 m_nxt = mp[(size_t)tp * D + mxi];
             }
+            M40F_STAMP(3);
         }
     }
 }

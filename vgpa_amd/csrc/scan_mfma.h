@@ -23,10 +23,13 @@
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
 #ifdef VGPA_STAMPS
-__device__ unsigned long long g_m40_stamps[64];
+__device__ unsigned long long g_m40_stamps[128];
 #define M40_STAMP(k) do { if (blockIdx.x == 7 && t == 1000 && lane == 0) g_m40_stamps[wid * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// fused kernel: eight wavefronts, stamps of steps t = 1000 (slots 0..7) and t = 999 (slots 8..15)
+#define M40F_STAMP(k) do { if (blockIdx.x == 7 && (t == 1000 || t == 999) && lane == 0) g_m40_stamps[wid * 16 + (t == 999 ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define M40_STAMP(k) do { } while (0)
+#define M40F_STAMP(k) do { } while (0)
 #endif
 
 struct M40 {
