@@ -40,6 +40,9 @@ ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false>"
 KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel", "esde": ESDE_KERNEL,
                 "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
+STREAM_FILE = os.path.join(ROOT, "profiles", "r2_hbm_stream_probe.txt")
+# read / write streams of each kernel, as tools/diag/hbm_stream_probe names the mixes
+STREAM_MIX = {"fwd_scan": "1R1W", "esde": "2R1W", "bwd_scan_grad": "3R2W"}
 
 
 def synth_problem(D, N, dt, P, seed, dev):
@@ -124,6 +127,21 @@ def cpu_baseline(D, dt, seconds_target=12.0):
                 sample=f"{cores} processes x 1 problem x {n} time steps x {repeat} evaluation(s) of the same "
                        f"Lorenz-96 D={D} free energy + gradient, NumPy oracle, 1 BLAS thread each, "
                        f"{max(times):.1f} s of work per process ({wall:.1f} s wall incl. start-up)")
+
+
+def stream_rate(mix):
+    """GB/s of the best plain streaming kernel with this mix of read and write streams on the same
+    part (tracked output of tools/diag/hbm_stream_probe), or None."""
+    best = None
+    try:
+        with open(STREAM_FILE) as f:
+            for ln in f:
+                w = ln.split()
+                if len(w) >= 5 and w[0] == mix and w[-1] == "GB/s":
+                    best = max(best or 0.0, float(w[-2]))
+    except (OSError, ValueError):
+        return None
+    return best
 
 
 def measured_traffic_per_unit(kernel):
@@ -309,7 +327,11 @@ def main():
                 """The roofline object of kernel k: algorithmic bytes per launch over its measured
                 average duration, and the HBM traffic the counters of the tracked profile give."""
                 t = measured_traffic_per_unit(KERNEL_NAMES[k])
+                sr = stream_rate(STREAM_MIX[k])
                 return {"kernel": KERNEL_NAMES[k], "bound": "hbm", "achieved": kernels[k]["achieved_GBps"],
+                        "stream_same_mix": None if sr is None else
+                        {"mix": STREAM_MIX[k], "GBps": sr, "frac_of_it": kernels[k]["achieved_GBps"] / sr,
+                         "source": os.path.relpath(STREAM_FILE, ROOT)},
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[k]["frac"],
                         "traffic": None if t is None else t * units_per_launch,
                         "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if t is not None else None,
