@@ -77,6 +77,14 @@ extern "C" {
                                        (it is when it came from vgpa_fwd_scan with
                                        VGPA_SCAN_SYMMETRIC)                                     */
 
+#define VGPA_SCAN_PSI_ROW0 4     /* vgpa_bwd_scan_grad only, and only where
+                                    vgpa_bwd_scan_grad_is_fused() holds: Psi_out is
+                                    (P,1,D,D) and receives Psi(0) alone -- the row the
+                                    gradient w.r.t. S0 needs (core/kl0.py:63-66); the
+                                    other rows are consumed inside the kernel and not
+                                    written (19 % of its memory traffic).  For callers
+                                    that only want F and the gradient, e.g. an optimiser. */
+
 /* largest state dimension the n-D kernels accept */
 #define VGPA_MAX_D 60
 
@@ -129,7 +137,7 @@ int vgpa_bwd_scan(int method, int P, int N, int D,
  * LDS, so that neither is read from memory a second time (used from 161 problems on, where the
  * call is bound by memory traffic); every other configuration runs the two kernels one after the
  * other.
- *   -> lam_out (P,N,D), Psi_out (P,N,D,D), gLA (P,N,D,D), gLb (P,N,D).
+ *   -> lam_out (P,N,D), Psi_out (P,N,D,D) [(P,1,D,D) with VGPA_SCAN_PSI_ROW0], gLA (P,N,D,D), gLb (P,N,D).
  */
 int vgpa_bwd_scan_grad(int method, int P, int N, int D,
                        const double* A, const double* b, const double* m, const double* S,
@@ -142,6 +150,15 @@ int vgpa_bwd_scan_grad(int method, int P, int N, int D,
                        double dt, int scan_flags, int grad_flags,
                        const double* lam_last, const double* Psi_last,
                        double* lam_out, double* Psi_out, double* gLA, double* gLb, void* stream);
+
+/*
+ * Whether vgpa_bwd_scan_grad runs as one kernel for these arguments (1) or as vgpa_bwd_scan followed
+ * by vgpa_grad_assemble (0); dense_jumps: dEobs_dS != NULL, explicit_edf: Edf != NULL.  No
+ * counterpart in the reference (it has one code path); a caller needs it to know whether
+ * VGPA_SCAN_PSI_ROW0 is accepted.  Touches no device.
+ */
+int vgpa_bwd_scan_grad_is_fused(int method, int P, int D, int scan_flags, int grad_flags,
+                                int dense_jumps, int explicit_edf, int edf_system);
 
 /*
  * Per-time-step expected SDE energy and its gradients: replaces the loop body of

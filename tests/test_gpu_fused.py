@@ -144,3 +144,34 @@ def test_fused_evaluation_at_the_benchmark_size():
     assert int(st.status.max().item()) == 0
     assert torch.equal(st2.Psi, st.Psi) and torch.equal(st2.lam, st.lam) and torch.equal(fb, gLb)
     assert relerr(fA.cpu().numpy(), gLA.cpu().numpy()) <= 1e-12
+
+
+@pytest.mark.parametrize("N", [1, 2, 9])
+def test_fused_evaluation_without_costate_rows(N):
+    """costate=False: the one-kernel path stores Psi(0) only; F, lam and the gradient are the same
+    bits as with every row stored.  Where the library runs two kernels the argument changes nothing."""
+    import torch
+    from vgpa_amd import engine, _lib
+    prob, A, b = _l96_problem(N, FUSED_P, 300 + N)
+    st, gLA, gLb = engine.free_energy_and_gradient(prob, A, b)
+    st2, fA, fb = engine.free_energy_and_gradient(prob, A, b, costate=False)
+    assert st2.Psi.shape == (FUSED_P, 1, 40, 40)
+    assert torch.equal(st2.Psi[:, 0], st.Psi[:, 0]) and torch.equal(st2.lam, st.lam) and torch.equal(st2.F, st.F)
+    assert torch.equal(fA, gLA) and torch.equal(fb, gLb)
+    # fewer problems than the one-kernel path takes: every row is there
+    small, As, bs = _l96_problem(N, 3, 300 + N)
+    st3, _, _ = engine.free_energy_and_gradient(small, As, bs, costate=False)
+    assert st3.Psi.shape == (3, N, 40, 40)
+    sf = _lib.SCAN_SYMMETRIC | _lib.SCAN_STATE_SYMMETRIC
+    assert _lib.lib.vgpa_bwd_scan_grad_is_fused(small.method, FUSED_P, 40, sf, _lib.GRAD_SIGINV_DIAG, 0, 0, _lib.SYS_L96_UT) == 1
+    assert _lib.lib.vgpa_bwd_scan_grad_is_fused(small.method, 3, 40, sf, _lib.GRAD_SIGINV_DIAG, 0, 0, _lib.SYS_L96_UT) == 0
+    # the flag itself is refused where the assembly kernel needs every row
+    en = dict(dEdm=st3.dEdm, dEdS=st3.dEdS)
+    lam, Psi = torch.empty_like(st3.dEdm), torch.empty((3, 1, 40, 40), dtype=torch.float64, device=As.device)
+    gA, gb = torch.empty_like(As), torch.empty_like(bs)
+    p_ = engine._p
+    with pytest.raises(_lib.VgpaError, match="VGPA_SCAN_PSI_ROW0"):
+        _lib.call("vgpa_bwd_scan_grad", small.method, 3, N, 40, p_(As), p_(bs), p_(st3.m), p_(st3.S), p_(en["dEdm"]),
+                  p_(en["dEdS"]), p_(st3.dEobs_dm), None, p_(small.obs_flag), p_(st3.jumpS), 0, p_(st3.Ef), None,
+                  small.system, p_(small.theta), 1, p_(small.SigInv), 0, float(small.dt), sf | _lib.SCAN_PSI_ROW0,
+                  _lib.GRAD_SIGINV_DIAG, None, None, p_(lam), p_(Psi), p_(gA), p_(gb), None)

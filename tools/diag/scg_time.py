@@ -13,8 +13,7 @@ nit = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 A, b, sde, m0, S0, thetas = bench.synth_problem(D, N, dt, P, 1, dev)
 prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P, theta=thetas)
 def ev():
-    st = engine.free_energy(prob, A, b, want_edf=False)
-    return engine.gradient(prob, A, b, st)
+    return engine.free_energy_and_gradient(prob, A, b)
 ev(); torch.cuda.synchronize()
 t0 = time.perf_counter(); ev(); torch.cuda.synchronize(); t_eval = time.perf_counter() - t0
 scg_batched(prob, A, b, nit=2); torch.cuda.synchronize()

@@ -28,6 +28,7 @@ ST_CHOL_FALLBACK, ST_CHOL_FAILED, ST_UNSUPPORTED = 1, 2, 4
 GRAD_OUTER, GRAD_SIGINV_DIAG = 1, 2
 SCAN_SYMMETRIC = 1
 SCAN_STATE_SYMMETRIC = 2
+SCAN_PSI_ROW0 = 4
 MAX_D = 60
 OBS_STATIC_MAX = 1 << 17
 
@@ -43,6 +44,7 @@ SIGNATURES = {
                       _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "vgpa_bwd_scan_grad": [_c_int] * 4 + [_ptr] * 9 + [_ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                            _c_dbl, _c_int, _c_int] + [_ptr] * 7,
+    "vgpa_bwd_scan_grad_is_fused": [_c_int] * 8,
     "vgpa_esde": [_c_int] + _ESDE_ARGS,
     "vgpa_esde_ou": _ESDE_ARGS,
     "vgpa_esde_dw": _ESDE_ARGS,

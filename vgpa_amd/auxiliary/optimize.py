@@ -420,7 +420,7 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
         """F at the parameter array v; the gradient goes into g_out."""
         A, b = ops.parts(v)
         if evaluate is None:
-            st, _, _ = engine.free_energy_and_gradient(prob, A, b, out=ops.parts(g_out))
+            st, _, _ = engine.free_energy_and_gradient(prob, A, b, out=ops.parts(g_out), costate=False)
             return st.F
         F, grad = evaluate(A, b, True)
         gA, gb = ops.rows(g_out)

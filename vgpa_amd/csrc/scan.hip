@@ -978,6 +978,17 @@ extern "C" int vgpa_bwd_scan(int method, int P, int N, int D, const double* A, c
     return vgpa::check_launch("vgpa_bwd_scan");
 }
 
+extern "C" int vgpa_bwd_scan_grad_is_fused(int method, int P, int D, int scan_flags, int grad_flags, int dense_jumps,
+                                           int explicit_edf, int edf_system) {
+    // One workgroup per problem: below about 160 problems the chip is not full, a step's latency
+    // and not the memory traffic sets the time, and the separate scan (shorter step) followed by the
+    // fully parallel assembly kernel is faster (measured: 6.5 against 7.9 ms at 128 problems, 9.4
+    // against 8.4 ms at 256, N = 2002).
+    return P > 160 && method == VGPA_EULER && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
+           (scan_flags & VGPA_SCAN_STATE_SYMMETRIC) && !dense_jumps && !explicit_edf && edf_system == VGPA_SYS_L96_UT &&
+           (grad_flags & VGPA_GRAD_SIGINV_DIAG) && !(grad_flags & VGPA_GRAD_OUTER);
+}
+
 extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double* A, const double* b, const double* m,
                                   const double* S, const double* dEsde_dm, const double* dEsde_dS,
                                   const double* dEobs_dm, const double* dEobs_dS, const int* obs_flag,
@@ -990,13 +1001,11 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
     VGPA_REQUIRE(P >= 0 && N >= 1 && D >= 1, "vgpa_bwd_scan_grad: bad sizes P=%d N=%d D=%d", P, N, D);
     VGPA_REQUIRE(A && b && m && S && dEsde_dm && dEsde_dS && dEobs_dm && Ef && SigInv && lam_out && Psi_out && gLA && gLb,
                  "vgpa_bwd_scan_grad: null pointer argument");
-    // One workgroup per problem: below about 160 problems the chip is not full, a step's latency
-    // and not the memory traffic sets the time, and the separate scan (shorter step) followed by the
-    // fully parallel assembly kernel is faster (measured: 6.5 against 7.9 ms at 128 problems, 9.4
-    // against 8.4 ms at 256, N = 2002).
-    const bool fused = P > 160 && method == VGPA_EULER && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
-                       (scan_flags & VGPA_SCAN_STATE_SYMMETRIC) && !dEobs_dS && !Edf && edf_system == VGPA_SYS_L96_UT &&
-                       (grad_flags & VGPA_GRAD_SIGINV_DIAG) && !(grad_flags & VGPA_GRAD_OUTER);
+    const bool fused = vgpa_bwd_scan_grad_is_fused(method, P, D, scan_flags, grad_flags, dEobs_dS != nullptr,
+                                                   Edf != nullptr, edf_system) != 0;
+    if (!fused && (scan_flags & VGPA_SCAN_PSI_ROW0))
+        return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan_grad: VGPA_SCAN_PSI_ROW0 is accepted only where "
+                          "vgpa_bwd_scan_grad_is_fused() holds (the assembly kernel needs every row of Psi)");
     if (!fused) {
         // every other configuration: the scan, then the assembly kernel
         const int rc = vgpa_bwd_scan(method, P, N, D, A, dEsde_dm, dEsde_dS, dEobs_dm, dEobs_dS, obs_flag, jumpS,
@@ -1015,7 +1024,7 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
     if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan_grad: the LDS size this launch needs was refused");
     hipLaunchKernelGGL(bwd_grad_euler_sym_mfma40_kernel, dim3(P), dim3(M40F::NT), lds, vgpa::as_stream(stream), N, A, b, m,
                        S, dEsde_dm, dEsde_dS, dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt,
-                       lam_last, Psi_last, lam_out, Psi_out, gLA, gLb);
+                       lam_last, Psi_last, lam_out, Psi_out, (scan_flags & VGPA_SCAN_PSI_ROW0) ? 0 : 1, gLA, gLb);
     return vgpa::check_launch("vgpa_bwd_scan_grad");
 }
 

@@ -128,7 +128,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                                  const double* __restrict__ jumpS, int jumpS_stride,
                                  const double* __restrict__ Efv, const double* __restrict__ SigInv, int sig_stride,
                                  double dt, const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
-                                 double* __restrict__ lam_out, double* __restrict__ Psi_out,
+                                 double* __restrict__ lam_out, double* __restrict__ Psi_out, int psi_all,
                                  double* __restrict__ gLA, double* __restrict__ gLb) {
     constexpr int D = M40::D, LD = M40::LD, MS = M40::MS, DD = M40::DD;
     extern __shared__ double lds[];
@@ -152,7 +152,8 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
     const double* mp = mvec + (size_t)p * N * D;
     const double* efp = Efv + (size_t)p * N * D;
     double* lo = lam_out + (size_t)p * N * D;
-    double* Po = Psi_out + (size_t)p * N * DD;
+    // psi_all == 0: Psi_out is (P, 1, D, D) and receives row 0 only
+    double* Po = Psi_out + (size_t)p * (psi_all ? N : 1) * DD;
     double* gAo = gLA + (size_t)p * N * DD;
     double* gbo = gLb + (size_t)p * N * D;
     const int vl = min(lane, D - 1);
@@ -164,7 +165,8 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
         const double* A0 = Ap + last * DD;
         const double* G0 = gS + last * DD;
         const double* S0 = Sp + last * DD;
-        double* P0 = Po + last * DD;
+        double* P0 = Po + (psi_all ? last : 0) * DD;
+        const bool store_last = psi_all || N == 1;
         for (int e = tid; e < DD; e += M40F::NT) {
             const int row = e / D, col = e % D;
             At[col * LD + row] = A0[e];
@@ -172,7 +174,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
             Sb[row * LD + col] = S0[e];
             const double pv = Psi_last ? Psi_last[(size_t)p * DD + e] : 0.0;
             Pb[row * LD + col] = pv;
-            P0[e] = pv;
+            if (store_last) P0[e] = pv;
         }
         if (tid < 48) mx[tid] = mp[last * D + (tid + D - 2) % D];
         if (tid >= 64 && tid < 64 + D) siv[tid - 64] = SigInv[(size_t)p * sig_stride + (size_t)(tid - 64) * (D + 1)];
@@ -241,7 +243,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
         for (int t = N - 1; t >= 0; --t) {
             __syncthreads();                   // Psi[t], A[t]', lam[t] are in LDS
             M40F_STAMP(0);
-            if (t < N - 1) M40Rows::write_out(Pb, lane, Po + (size_t)t * DD);
+            if (t < N - 1 && (psi_all || t == 0)) M40Rows::write_out(Pb, lane, Po + (size_t)t * DD);
             double lnew = 0.0;
             if (t >= 1 && lane < D) {
                 double d0 = 0.0, d1 = 0.0;     // (A lam)[lane] = sum_q At[q][lane] lam[q]

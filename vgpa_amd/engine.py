@@ -269,14 +269,26 @@ def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, 
 
 
 def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, dEobs_dS=None, symmetric=False,
-                  state_symmetric=False, outer=False, lam_last=None, Psi_last=None, out=None):
+                  state_symmetric=False, outer=False, lam_last=None, Psi_last=None, out=None, costate=True):
     """vgpa_bwd_scan_grad -> lam, Psi, gLA, gLb: the backward scan and the gradient assembly
     in one call.  With the Euler method at D = 40, symmetric inputs (``symmetric``: dEdS and
     the jumps; ``state_symmetric``: S), an implicit Lorenz-96 <df/dx> (Edf None) and a diagonal
-    SigInv one kernel does both; otherwise the library runs the two kernels in sequence."""
+    SigInv one kernel does both; otherwise the library runs the two kernels in sequence.
+
+    ``costate=False``: the caller does not need Psi(t) beyond t = 0 (an optimiser wants F and the
+    gradient only).  Where the one-kernel path runs, Psi then comes back as (P, 1, D, D) holding
+    Psi(0) and the other rows are never written; elsewhere the argument changes nothing."""
     P, N, D = prob.P, prob.N, prob.D
     lam = torch.empty_like(dEdm)
-    Psi = torch.empty_like(dEdS)
+    sflags = (_lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0) | \
+             (_lib.SCAN_STATE_SYMMETRIC if (state_symmetric and D > 1) else 0)
+    gflags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
+    if not costate and _lib.lib.vgpa_bwd_scan_grad_is_fused(prob.method, P, D, sflags, gflags, int(dEobs_dS is not None),
+                                                           int(Edf is not None), prob.system):
+        sflags |= _lib.SCAN_PSI_ROW0
+        Psi = torch.empty((P, 1, D, D), dtype=F64, device=dEdS.device)
+    else:
+        Psi = torch.empty_like(dEdS)
     if out is None:
         gLA, gLb = torch.empty_like(A), torch.empty_like(b)
     else:
@@ -286,9 +298,6 @@ def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, d
     jstride = 0
     if jumpS is not None and jumpS.numel() == P * D * D and P > 1:
         jstride = D * D
-    sflags = (_lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0) | \
-             (_lib.SCAN_STATE_SYMMETRIC if (state_symmetric and D > 1) else 0)
-    gflags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
     n_theta = 3 if prob.system in (_lib.SYS_L63, _lib.SYS_L63_UT) else 1
     call("vgpa_bwd_scan_grad", prob.method, P, N, D, _p(A), _p(b), _p(m), _p(S), _p(dEdm), _p(dEdS), _p(dEobs_dm),
          _p(dEobs_dS), _p(prob.obs_flag), _p(jumpS), jstride, _p(Ef), _p(Edf), prob.system, _p(prob.theta),
@@ -535,10 +544,11 @@ def gradient(prob, A, b, st, outer=False, out=None):
     return grad_assemble(prob, A, b, st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf, outer=outer, out=out)
 
 
-def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer=False, out=None):
+def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer=False, out=None, costate=True):
     """core/varFreeEnergy.py:80-111 followed by core/gradL_Ab.py:156-180 for a batch, with the
     backward scan and the gradient assembly in one library call (one kernel for the Lorenz-96
-    D = 40 Euler case, see ``bwd_scan_grad``).  Returns (State, gLA, gLb)."""
+    D = 40 Euler case, see ``bwd_scan_grad``).  Returns (State, gLA, gLb).  ``costate=False``: State.Psi
+    may hold row 0 only (see ``bwd_scan_grad``); for callers that use F and the gradient alone."""
     if prob.system < 0:
         st = free_energy(prob, A, b, want_hyper=want_hyper, want_edf=True)
         gLA, gLb = gradient(prob, A, b, st, outer=outer, out=out)
@@ -550,7 +560,8 @@ def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer
                       want_hyper, want_edf=want_edf or not implicit_ok)
     sym = prob.sym_jump and esde_output_is_symmetric(prob.system, prob.D)
     lam, Psi, gLA, gLb = bwd_scan_grad(prob, A, b, m, S, en["dEdm"], en["dEdS"], dEobs_dm, en["Ef"], en["Edf"],
-                                       jumpS=jumpS, symmetric=sym, state_symmetric=prob.sym_fwd, outer=outer, out=out)
+                                       jumpS=jumpS, symmetric=sym, state_symmetric=prob.sym_fwd, outer=outer, out=out,
+                                       costate=costate)
     KL0 = kl0(prob)
     F = KL0 + Eobs + en["Esde"]
     st = State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"], Edf=en["Edf"],
