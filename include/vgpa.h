@@ -340,7 +340,11 @@ int vgpa_mom_gauss(long long n, const double* m, const double* S, int order, int
  *                      sum|g_try|}.
  * vgpa_scg_update      mode bit 0: x <- x_try, g <- g_try (:188-195); then d <- -g when
  *                      bit 1 is set (restart, :216-218), else gamma[p]*d - g (:222);
- *                      out = {d.g, d.d, g.g} of the new pair.
+ *                      out = {d.g, d.d, g.g} of the new pair.  Bit 2 (4): the same new
+ *                      direction from g as it stands, without the copy -- for a caller that
+ *                      exchanges its (x, g) and (x_try, g_try) arrays instead of copying
+ *                      accepted points; bit 3 (8): the copy alone (d untouched, out = 0), for
+ *                      the rows such an exchange must not move.
  */
 int vgpa_scg_dots(int P, long long nA, long long nb, const double* d, const double* g,
                   const int* mode, int nch, double* work, double* out, void* stream);

@@ -64,15 +64,25 @@ def test_passes_match_torch_statement(P, shape_A, shape_b):
     assert torch.equal(a[:, 0], b[:, 0])
     _close(a[:, 1:], b[:, 1:], n * 10.0)
 
-    # update: all four combinations of (moved, restart)
-    um = (torch.arange(P, device=hip.dev) % 4).to(torch.int32)
-    s1 = [t.clone() for t in (x, g, d)]
-    s2 = [t.clone() for t in (x, g, d)]
-    a = hip.update(s1[0], xt, s1[1], gt, s1[2], coef, um)
-    b = ref.update(s2[0], xt, s2[1], gt, s2[2], coef, um)
-    for t1, t2 in zip(s1, s2):
-        assert torch.equal(t1, t2)
-    _close(a, b, n * 30.0)
+    # update: all four combinations of (moved, restart); then the modes of a caller that exchanges
+    # its arrays instead of copying: 4 (new direction from g as it stands), 6 (restart), 8 (copy only)
+    for um in ((torch.arange(P, device=hip.dev) % 4).to(torch.int32),
+               torch.tensor([0, 4, 6, 8], device=hip.dev, dtype=torch.int32)[torch.arange(P, device=hip.dev) % 4]):
+        s1 = [t.clone() for t in (x, g, d)]
+        s2 = [t.clone() for t in (x, g, d)]
+        a = hip.update(s1[0], xt, s1[1], gt, s1[2], coef, um)
+        b = ref.update(s2[0], xt, s2[1], gt, s2[2], coef, um)
+        for t1, t2 in zip(s1, s2):
+            assert torch.equal(t1, t2)
+        _close(a, b, n * 30.0)
+        assert torch.all(a[(um == 0) | (um == 8)] == 0)
+        for rx, rg, rd, x0, g0, d0, rxt, rgt in zip(hip.rows(s1[0]), hip.rows(s1[1]), hip.rows(s1[2]), hip.rows(x),
+                                                     hip.rows(g), hip.rows(d), hip.rows(xt), hip.rows(gt)):
+            keep = (um == 4) | (um == 6)            # x and g stay, d changes
+            assert torch.equal(rx[keep], x0[keep]) and torch.equal(rg[keep], g0[keep])
+            copied = um == 8                        # x and g are copied, d stays
+            assert torch.equal(rx[copied], rxt[copied]) and torch.equal(rg[copied], rgt[copied])
+            assert torch.equal(rd[copied], d0[copied])
     # repeated call on the same data: same bits
     assert torch.equal(hip.dots(d, g), hip.dots(d, g))
 

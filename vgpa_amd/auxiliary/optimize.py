@@ -378,12 +378,14 @@ class _TorchParamOps(_ParamVectors):
 
     def update(self, x, x_try, g, g_try, d, gamma, mode):
         import torch
-        moved, restart = ((mode & 1) != 0).unsqueeze(1), ((mode & 2) != 0).unsqueeze(1)
+        copy = ((mode & 9) != 0).unsqueeze(1)                   # bits 1, 8: x <- x_try, g <- g_try
+        restart = ((mode & 2) != 0).unsqueeze(1)
+        turn = ((mode & 5) != 0).unsqueeze(1)                    # bits 1, 4: new direction from the new g
         for xs, xt, gs, gt, ds in zip(self.rows(x), self.rows(x_try), self.rows(g), self.rows(g_try), self.rows(d)):
-            xs.copy_(torch.where(moved, xt, xs))
-            gs.copy_(torch.where(moved, gt, gs))
-            ds.copy_(torch.where(restart, -gs, torch.where(moved, gamma.unsqueeze(1) * ds - gs, ds)))
-        return self.dots(d, g, mode)
+            xs.copy_(torch.where(copy, xt, xs))
+            gs.copy_(torch.where(copy, gt, gs))
+            ds.copy_(torch.where(restart, -gs, torch.where(turn, gamma.unsqueeze(1) * ds - gs, ds)))
+        return self.dots(d, g, torch.where((mode & 8) != 0, torch.zeros_like(mode), mode))
 
 
 def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, disp=False):
@@ -397,7 +399,9 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     the probe points, one at the trial points (the reference evaluates F a third time
     at the accepted point, which is the trial point again: that value is reused), and
     five passes over the parameter arrays (vgpa_scg_step twice, vgpa_scg_curvature,
-    vgpa_scg_trial_stats, vgpa_scg_update).  The gradient before the last accepted step
+    vgpa_scg_trial_stats, vgpa_scg_update).  An accepted trial point and its gradient are not
+    copied: the arrays (x, g) and (x_try, g_try) change roles, and only the rows of problems that
+    did not move are copied back (15 array traversals per iteration instead of 18).  The gradient before the last accepted step
     is needed only through sum|g| (the 'gradx' column), which is kept as a scalar.
 
     ``evaluate(A, b, need_grad)`` -> (F (P,), grad (P,n) or None) replaces the device
@@ -465,6 +469,7 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     for j in range(nit):
         if not bool(active.any().item()):
             break
+        live0 = active.clone()
         probe = accepted & active
         # slope / curvature for the problems whose last step was accepted (optimize.py:150-156)
         dg, dd, gg = slopes[:, 0], slopes[:, 1], slopes[:, 2]
@@ -524,8 +529,20 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
 
         restart = active & (n_acc == n)
         gamma = torch.where(moved, torch.clamp(trial[:, 2] / mu, min=0.0), zeros)
-        # every accepted problem moves (also one that has just finished: its x is final)
-        slopes = ops.update(x, y, g, g_try, d, gamma, ok.to(i32) + 2 * restart.to(i32))
+        # Every accepted problem moves (also one that has just finished: its x is final).  The
+        # arrays change roles instead of being copied: (y, g_try) become (x, g).  Rows that must not
+        # move are copied back: problems that were live at the top of this iteration and were not
+        # accepted (rejected, or finished before the step).  Rows of problems that finished on an
+        # accepted step are copied the other way, so that a finished problem has the same rows in
+        # both sets and later exchanges leave it alone.
+        x, y, g, g_try = y, x, g_try, g
+        stay = live0 & ~ok
+        if bool(stay.any().item()):
+            ops.update(x, y, g, g_try, d, zeros, 8 * stay.to(i32))
+        done = ok & ~active
+        if bool(done.any().item()):
+            ops.update(y, x, g_try, g, d, zeros, 8 * done.to(i32))
+        slopes = ops.update(x, y, g, g_try, d, gamma, 4 * ok.to(i32) + 2 * restart.to(i32))
         n_acc = torch.where(restart, torch.zeros_like(n_acc), n_acc)
 
     # problems that ran out of iterations report the last accepted value (optimize.py:245)

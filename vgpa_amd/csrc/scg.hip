@@ -128,10 +128,15 @@ struct TrialStats {
     }
 };
 
-// After the accept / reject decision (mode bit 0 = the problem moves to the trial point,
-// bit 1 = restart): x <- x_try, g <- g_try (:188-195), then the new direction
-// d <- -g (restart, :216-218) or gamma d - g (:221-222).  Also returns {d.g, d.d, g.g} of
-// the new pair, which is what the next iteration starts from.
+// After the accept / reject decision.  Mode bits:
+//   1  the problem moves to the trial point: x <- x_try, g <- g_try (optimize.py:188-195), then
+//      the new direction from the new g
+//   2  restart: d <- -g (:216-218) instead of d <- gamma d - g (:221-222)
+//   4  the new direction from g as it stands: for a caller that has exchanged its (x, g) and
+//      (x_try, g_try) arrays instead of copying, so that x and g already hold the accepted point
+//   8  copy only: x <- x_try, g <- g_try, d untouched, results zero (rows that the exchange
+//      must not move: rejected and finished problems)
+// Returns {d.g, d.d, g.g} of the new pair, which is what the next iteration starts from.
 struct Update {
     static constexpr int K = 3;
     static constexpr unsigned MAXMASK = 0;
@@ -140,12 +145,17 @@ struct Update {
     template <int V> struct In { Vec<V> xt, g, d; };
     template <int V> __device__ In<V> load(size_t at, int md) const {
         In<V> in;
-        in.g = Vec<V>::load(((md & 1) ? gt : g) + at);
-        if (md & 1) in.xt = Vec<V>::load(xt + at);
-        if (!(md & 2)) in.d = Vec<V>::load(d + at);
+        in.g = Vec<V>::load(((md & 9) ? gt : g) + at);
+        if (md & 9) in.xt = Vec<V>::load(xt + at);
+        if (!(md & 10)) in.d = Vec<V>::load(d + at);
         return in;
     }
     template <int V> __device__ void apply(const In<V>& in, size_t at, int p, int md, double (&acc)[4]) const {
+        if (md & 9) {
+            in.xt.store(x + at);
+            in.g.store(g + at);
+        }
+        if (md & 8) return;
         const double gm = gamma[p];
         Vec<V> dn;
         for (int i = 0; i < V; ++i) {
@@ -153,10 +163,6 @@ struct Update {
             acc[0] += dn.v[i] * in.g.v[i];
             acc[1] += dn.v[i] * dn.v[i];
             acc[2] += in.g.v[i] * in.g.v[i];
-        }
-        if (md & 1) {
-            in.xt.store(x + at);
-            in.g.store(g + at);
         }
         dn.store(d + at);
     }
