@@ -1,3 +1,7 @@
+// EXPERIMENT RECORD, not built: the energy kernel with phase 4 (G = A L' and the sigma-point residuals) split by
+// column block and run inside the waits of the diagonal-block factorisation.  Correct, and slower: 12.9 ms
+// against 11.35 ms (the windows of the mean are formed three times, 256 registers with two spilled, and a
+// scratch reload waits for the A fragments still in flight).
 // Lorenz-96 unscented energy kernel for D = 40: ONE WAVEFRONT per (problem, time step),
 // eight steps in flight per CU, the matrix products on the FP64 matrix cores.  Workgroups are
 // pairs of wavefronts (two consecutive steps) that share nothing but the factorisation of the
@@ -410,17 +414,19 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     double a0 = 0.0;          // squared centre-point residual of component `lane`
     // ---- phase 3: <f>, A m - b.  Independent of the factor, so each wavefront runs it while its
     // partner factors a diagonal block for both steps (wavefront 1 during block 0, wavefront 0
-    // during block 1) instead of waiting at the barrier.
+    // during block 1) instead of waiting at the barrier; the column blocks of phase 4 that are
+    // ready follow it there (wavefront 0: block 0 during block 1; wavefront 1: blocks 0 and 1
+    // during block 2).
     auto phase3 = [&]() __attribute__((always_inline)) {
         WV_RELANE();
         {
             double mk[10];
-#pragma unroll
+    #pragma unroll
             for (int s = 0; s < 10; ++s) mk[s] = mv[4 * s + g4];
-#pragma unroll
+    #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 double t0 = 0.0, t1 = 0.0;
-#pragma unroll
+    #pragma unroll
                 for (int s = 0; s < 10; s += 2) {
                     t0 = fma(af[i][s], mk[s], t0);
                     t1 = fma(af[i][s + 1], mk[s + 1], t1);
@@ -448,6 +454,79 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
         }
         wave_lds_fence();
     };
+    // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
+    // sigma-point pair 16 j + c16, summed over this lane's state indices
+    double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
+    double mb[3][4] = {};
+    // ---- phase 4, one column block j of G = A L' and of the sigma-point residuals (pairs 16 j ..
+    // 16 j + 15).  It needs the columns 16 j .. 16 j + 15 of L' only, which are final once panel j is
+    // done: a wavefront runs it for the blocks that are ready while its partner factors the next
+    // diagonal block, and for the rest after the factorisation.
+    auto phase4_col = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
+        WV_RELANE();
+        // the B operands L'[4 s + g4][16 j + c16], s >= 4 j (L' is lower triangular: in the
+        // diagonal block the entries above the diagonal are read as zero)
+        double lb[10];
+        {
+            const int col = 16 * j + c16;
+#pragma unroll
+            for (int s = 4 * j; s < 10; ++s) {
+                const int k = 4 * s + g4;
+                lb[s] = *((s < 4 * j + 4 && k < col) ? zslot : buf + k * LD + col);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            wv_f64x4 G = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 4 * j; s < 10; ++s) G = wv_mfma(af[i][s], lb[s], G);
+            const int d0r = 16 * i + 4 * g4;
+            const bool rows_valid = d0r < D;
+            const int d0 = rows_valid ? d0r : D - 4;
+            // window rows d0 - 2 .. d0 + 4 on the ring: only the first lane group of tile row 0
+            // (rows -2, -1) and the lanes with d0 = 36 (row 40) wrap
+            int rw[7];
+            double mm[7];
+#pragma unroll
+            for (int w = 0; w < 7; ++w) {
+                rw[w] = d0 - 2 + w;
+                mm[w] = mvx[d0 + w];
+            }
+            if (i == 0) {
+                const int fix = (g4 == 0) ? D : 0;
+                rw[0] += fix;
+                rw[1] += fix;
+            }
+            if (i == 2) rw[6] -= (d0 == D - 4) ? D : 0;
+            const int col = min(16 * j + c16, D - 1);
+            const bool col_valid = 16 * j + c16 < D;
+            double o[7];
+#pragma unroll
+            for (int w = 0; w < 7; ++w) {
+                o[w] = *((rw[w] >= col) ? buf + rw[w] * LD + col : zslot);      // L' is lower triangular
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // per state index d = d0 + q (position q + 2 of the window): the drift at the mean
+                // plus A m - b, and the two mean factors of the quadratic term
+                const double aq = mm[q + 3] - mm[q], bq = mm[q + 1];
+                const double kq = fma(aq, bq, theta - mm[q + 2]) + basev[d0 + q];
+                const double si = rows_valid ? sIv[d0 + q] : 0.0;
+                // With x+- = m +- o the residuals of the two sigma points are
+                //   r+- = (a +- de)(b +- ep) - (m0 +- o0) + theta + base +- c G
+                // so  (r+ + r-)/2 = k + de ep   and   (r+ - r-)/2 = a ep + de b - o0 + G'  (G' = A L' = c G).
+                const double de = o[q + 3] - o[q], ep = o[q + 1];
+                const double sp = fma(de, ep, kq);
+                const double dp = fma(aq, ep, fma(de, bq, G[q] - o[q + 2]));
+                const double t = fma(dp, dp, sp * sp);             // (r+^2 + r-^2) / 2
+                hp[j] = fma(si, t, hp[j]);
+                hq[j] = fma(si * sp, dp, hq[j]);                   // (r+^2 - r-^2) / 4
+                if (HYPER) mb[i][q] += col_valid ? 2.0 * w1 * t : 0.0;
+            }
+            wave_lds_fence();          // keeps the LDS reads of one tile together (register pressure)
+        }
+    };
     bool ok = true;
     // diagonal block J of both steps by wavefront J & 1
 #define WV_FACTOR_BOTH(J)                                                            \
@@ -457,8 +536,10 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             const int r = wv_factor_diag<J>(buf, zslot, other, lane);                \
             ok = ok && (r & 1);                                                      \
             if (lane == 0 && !(r & 2)) pd_flags[1 - wv] = 0;                         \
-        } else if ((J) < 2) {                                                        \
-            phase3();                                                                \
+        } else {                                                                     \
+            if ((J) < 2) phase3();                                                   \
+            if ((J) >= 1) phase4_col(std::integral_constant<int, 0>{});              \
+            if ((J) == 2) phase4_col(std::integral_constant<int, 1>{});              \
         }                                                                            \
         __syncthreads();                                                             \
     } while (0)
@@ -543,10 +624,6 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
 
     WV_STAMP(18);
     WV_RELANE();
-    // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
-    // sigma-point pair 16 j + c16, summed over this lane's state indices
-    double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
-    double mb[3][4] = {};
     // ---- phase 3 has run inside the factorisation (see phase3 above); the dense <df/dx> if wanted ----
     if (a.Edf) {
         // Jacobian of the drift at the mean; row i is filled in the order
@@ -583,87 +660,10 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     WV_STAMP(19);
 
     WV_RELANE();
-    // ---- phase 4: G = A L, then the sigma-point residuals ---------------------------------
-    // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
-    // sigma-point pair 16 j + c16, summed over this lane's state indices
-    {
-        // the B operands L'[4 s + g4][16 j + c16], s >= 4 j (L' is lower triangular: in the
-        // diagonal blocks the entries above the diagonal are read as zero)
-        double lb[3][10];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int col = 16 * j + c16;
-#pragma unroll
-            for (int s = 4 * j; s < 10; ++s) {
-                const int k = 4 * s + g4;
-                lb[j][s] = *((s < 4 * j + 4 && k < col) ? zslot : buf + k * LD + col);
-            }
-        }
-        // one tile row of G at a time (the three tiles of a row share the A fragments, and
-        // only 24 result registers are alive at once)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            wv_f64x4 G[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                G[j] = wv_f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s = 4 * j; s < 10; ++s) G[j] = wv_mfma(af[i][s], lb[j][s], G[j]);
-            }
-            const int d0r = 16 * i + 4 * g4;
-            const bool rows_valid = d0r < D;
-            const int d0 = rows_valid ? d0r : D - 4;
-            // window rows d0 - 2 .. d0 + 4 on the ring: only the first lane group of tile row 0
-            // (rows -2, -1) and the lanes with d0 = 36 (row 40) wrap
-            int rw[7];
-            double mm[7];
-#pragma unroll
-            for (int w = 0; w < 7; ++w) {
-                rw[w] = d0 - 2 + w;
-                mm[w] = mvx[d0 + w];
-            }
-            if (i == 0) {
-                const int fix = (g4 == 0) ? D : 0;
-                rw[0] += fix;
-                rw[1] += fix;
-            }
-            if (i == 2) rw[6] -= (d0 == D - 4) ? D : 0;
-            // per state index d = d0 + q (position q + 2 of the window): the drift at the mean
-            // plus A m - b, and the two mean factors of the quadratic term
-            double kq[4], aq[4], bq[4], si[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                aq[q] = mm[q + 3] - mm[q];
-                bq[q] = mm[q + 1];
-                kq[q] = fma(aq[q], bq[q], theta - mm[q + 2]) + basev[d0 + q];
-                si[q] = rows_valid ? sIv[d0 + q] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                wave_lds_fence();      // keeps the LDS reads of one tile together (register pressure)
-                const int col = min(16 * j + c16, D - 1);
-                const bool col_valid = 16 * j + c16 < D;
-                double o[7];
-#pragma unroll
-                for (int w = 0; w < 7; ++w) {
-                    o[w] = *((rw[w] >= col) ? buf + rw[w] * LD + col : zslot);      // L' is lower triangular
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // With x+- = m +- o the residuals of the two sigma points are
-                    //   r+- = (a +- de)(b +- ep) - (m0 +- o0) + theta + base +- c G
-                    // so  (r+ + r-)/2 = k + de ep   and   (r+ - r-)/2 = a ep + de b - o0 + G'  (G' = A L' = c G).
-                    const double de = o[q + 3] - o[q], ep = o[q + 1];
-                    const double sp = fma(de, ep, kq[q]);
-                    const double dp = fma(aq[q], ep, fma(de, bq[q], G[j][q] - o[q + 2]));
-                    const double t = fma(dp, dp, sp * sp);             // (r+^2 + r-^2) / 2
-                    hp[j] = fma(si[q], t, hp[j]);
-                    hq[j] = fma(si[q] * sp, dp, hq[j]);                // (r+^2 - r-^2) / 4
-                    if (HYPER) mb[i][q] += col_valid ? 2.0 * w1 * t : 0.0;
-                }
-            }
-        }
-    }
+    // ---- phase 4 (rest): the column blocks of G = A L' and of the residuals that did not fit into the
+    // waits of the factorisation: wavefront 0 has block 0 behind it, wavefront 1 blocks 0 and 1
+    if (wv == 0) phase4_col(std::integral_constant<int, 1>{});
+    phase4_col(std::integral_constant<int, 2>{});
     WV_STAMP(21);
     WV_RELANE();
     // ---- phase 5: Esde(t), u, g ------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include "linalg.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
