@@ -130,7 +130,7 @@ int vgpa_bwd_scan(int method, int P, int N, int D,
  * Backward scan and gradient assembly in one call: replaces core/bwd_ode.py:50 `solver(...)`
  * followed by core/gradL_Ab.py:112 `gradL_Ab_nD` (the loop :156-173 and the scaling :176-177),
  * i.e. vgpa_bwd_scan followed by vgpa_grad_assemble, with the arguments of both (scan_flags:
- * VGPA_SCAN_*; grad_flags: VGPA_GRAD_*).  For the Euler method at D = 40 with
+ * VGPA_SCAN_*; grad_flags: VGPA_GRAD_*).  For the Euler, Heun and RK2 methods at D = 40 with
  * VGPA_SCAN_SYMMETRIC | VGPA_SCAN_STATE_SYMMETRIC, flagged jumps (dEobs_dS == NULL), Edf ==
  * NULL with edf_system == VGPA_SYS_L96_UT and a diagonal SigInv without VGPA_GRAD_OUTER, one
  * kernel forms the gradient of a row while the scan has that row's A(t), Psi(t), lam(t) in

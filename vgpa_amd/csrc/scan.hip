@@ -773,6 +773,7 @@ void allow_lds(K kernel, size_t bytes) {
 #include "scan_mfma.h"
 #include "scan_mfma_stages.h"
 #include "scan_fused.h"
+#include "scan_fused_stages2.h"
 #define VGPA_SMALL_D_SCANS
 #include "small_d.h"
 
@@ -984,7 +985,7 @@ extern "C" int vgpa_bwd_scan_grad_is_fused(int method, int P, int D, int scan_fl
     // and not the memory traffic sets the time, and the separate scan (shorter step) followed by the
     // fully parallel assembly kernel is faster (measured: 6.5 against 7.9 ms at 128 problems, 9.4
     // against 8.4 ms at 256, N = 2002).
-    return P > 160 && method == VGPA_EULER && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
+    return P > 160 && (method == VGPA_EULER || method == VGPA_HEUN || method == VGPA_RK2) && D == 40 && (scan_flags & VGPA_SCAN_SYMMETRIC) &&
            (scan_flags & VGPA_SCAN_STATE_SYMMETRIC) && !dense_jumps && !explicit_edf && edf_system == VGPA_SYS_L96_UT &&
            (grad_flags & VGPA_GRAD_SIGINV_DIAG) && !(grad_flags & VGPA_GRAD_OUTER);
 }
@@ -1019,12 +1020,27 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
     VGPA_REQUIRE(sig_stride == 0 || sig_stride == D * D, "vgpa_bwd_scan_grad: sig_stride must be 0 or D*D");
     if (P == 0) return VGPA_OK;
     g_lds_refused = false;
+    const int psi_all = (scan_flags & VGPA_SCAN_PSI_ROW0) ? 0 : 1;
+    if (method != VGPA_EULER) {
+        const size_t lds = sizeof(double) * M40FH::LDS_DOUBLES;
+        auto launch = [&](auto kernel) {
+            allow_lds(kernel, lds);
+            if (g_lds_refused) return;
+            hipLaunchKernelGGL(kernel, dim3(P), dim3(M40FH::NT), lds, vgpa::as_stream(stream), N, A, b, m, S, dEsde_dm,
+                               dEsde_dS, dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt, lam_last,
+                               Psi_last, lam_out, Psi_out, psi_all, gLA, gLb);
+        };
+        if (method == VGPA_HEUN) launch(bwd_grad_stages2_sym_mfma40_kernel<VGPA_HEUN>);
+        else launch(bwd_grad_stages2_sym_mfma40_kernel<VGPA_RK2>);
+        if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan_grad: the LDS size this launch needs was refused");
+        return vgpa::check_launch("vgpa_bwd_scan_grad");
+    }
     const size_t lds = sizeof(double) * M40F::LDS_DOUBLES;
     allow_lds(bwd_grad_euler_sym_mfma40_kernel, lds);
     if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan_grad: the LDS size this launch needs was refused");
     hipLaunchKernelGGL(bwd_grad_euler_sym_mfma40_kernel, dim3(P), dim3(M40F::NT), lds, vgpa::as_stream(stream), N, A, b, m,
                        S, dEsde_dm, dEsde_dS, dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt,
-                       lam_last, Psi_last, lam_out, Psi_out, (scan_flags & VGPA_SCAN_PSI_ROW0) ? 0 : 1, gLA, gLb);
+                       lam_last, Psi_last, lam_out, Psi_out, psi_all, gLA, gLb);
     return vgpa::check_launch("vgpa_bwd_scan_grad");
 }
 
