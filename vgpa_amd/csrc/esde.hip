@@ -143,7 +143,7 @@ __device__ inline void l63_common_outputs(const EsdeArgs& a, size_t e, const L63
 // Lorenz-63 with analytic Gaussian moments: one lane per (problem, step).
 // Energy_dm_dS, dynamics/sys_lorenz_63.py:247-488.
 // ---------------------------------------------------------------------------
-__global__ void esde_l63_kernel(EsdeArgs a) {
+__global__ void __launch_bounds__(256) esde_l63_kernel(EsdeArgs a) {
     const size_t total = (size_t)a.P * a.N;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -260,7 +260,7 @@ __global__ void esde_l63_kernel(EsdeArgs a) {
 // diagonal Cholesky fallback of auxiliary/numerical.py:199-202.
 // dynamics/sys_lorenz_63_ut.py:218-255.
 // ---------------------------------------------------------------------------
-__global__ void esde_l63_ut_kernel(EsdeArgs a) {
+__global__ void __launch_bounds__(256) esde_l63_ut_kernel(EsdeArgs a) {
     const size_t total = (size_t)a.P * a.N;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;

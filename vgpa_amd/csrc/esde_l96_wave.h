@@ -546,7 +546,10 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     // hp[j] = sum_d Sigma^-1_d (r+^2 + r-^2)/2 and hq[j] = sum_d Sigma^-1_d (r+^2 - r-^2)/4 of
     // sigma-point pair 16 j + c16, summed over this lane's state indices
     double hp[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
-    double mb[3][4] = {};
+    // (three vector values, not an array: the array form ended up in scratch memory, whose reloads
+    // wait for the A fragments still in flight)
+    wv_f64x4 mb0 = {0.0, 0.0, 0.0, 0.0}, mb1 = mb0, mb2 = mb0;
+#define WV_MB(i) ((i) == 0 ? mb0 : ((i) == 1 ? mb1 : mb2))
     // ---- phase 3 has run inside the factorisation (see phase3 above); the dense <df/dx> if wanted ----
     if (a.Edf) {
         // Jacobian of the drift at the mean; row i is filled in the order
@@ -659,7 +662,12 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
                     const double t = fma(dp, dp, sp * sp);             // (r+^2 + r-^2) / 2
                     hp[j] = fma(si[q], t, hp[j]);
                     hq[j] = fma(si[q] * sp, dp, hq[j]);                // (r+^2 - r-^2) / 4
-                    if (HYPER) mb[i][q] += col_valid ? 2.0 * w1 * t : 0.0;
+                    if (HYPER) {
+                        const double add = col_valid ? 2.0 * w1 * t : 0.0;
+                        if (i == 0) mb0[q] += add;
+                        if (i == 1) mb1[q] += add;
+                        if (i == 2) mb2[q] += add;
+                    }
                 }
             }
         }
@@ -701,16 +709,20 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    mb[i][q] = wv_row_sum(mb[i][q]);
+                    const double rs = wv_row_sum(WV_MB(i)[q]);
+                    if (i == 0) mb0[q] = rs;
+                    if (i == 1) mb1[q] = rs;
+                    if (i == 2) mb2[q] = rs;
                 }
             // lane (g4, c16 == q) stores row 16 i + 4 g4 + q
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int d = 16 * i + 4 * g4 + c16;
-                double t = mb[i][0];
-                t = (c16 == 1) ? mb[i][1] : t;
-                t = (c16 == 2) ? mb[i][2] : t;
-                t = (c16 == 3) ? mb[i][3] : t;
+                const wv_f64x4 mbi = WV_MB(i);
+                double t = mbi[0];
+                t = (c16 == 1) ? mbi[1] : t;
+                t = (c16 == 2) ? mbi[2] : t;
+                t = (c16 == 3) ? mbi[3] : t;
                 // the centre point: w0 (f0 + base)^2 of component d, held by lane d
                 const double ctr = __shfl(a0, min(d, D - 1), 64);
                 if (c16 < 4 && 16 * i + 4 * g4 < D) a.dSig_t[e * D + d] = w0 * ctr + t;
@@ -892,4 +904,5 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     WV_STAMP(31);
 #endif
 #undef WV_RELANE
+#undef WV_MB
 }

@@ -407,7 +407,7 @@ struct LdsMap {
 // core/fwd_ode.py: euler_nD :87, heun_nD :181, rk2_nD :311, rk4_nD :426.
 // ---------------------------------------------------------------------------
 template <int METHOD, int DT, bool SYM>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(DT == 16 ? 64 : 512)
 fwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* __restrict__ b,
                    const double* __restrict__ m0, const double* __restrict__ S0,
                    const double* __restrict__ Sigma, int sigma_stride, double dt,
@@ -562,7 +562,7 @@ fwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* _
 // core/bwd_ode.py: euler_nD :86, heun_nD :177, rk2_nD :305, rk4_nD :427.
 // ---------------------------------------------------------------------------
 template <int METHOD, int DT, bool SYM>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(DT == 16 ? 64 : 512)
 bwd_scan_nd_kernel(int N, int Drt, const double* __restrict__ A, const double* __restrict__ dEdm,
                    const double* __restrict__ dEdS, const double* __restrict__ jm,
                    const double* __restrict__ jS_dense, const int* __restrict__ obs_flag,
