@@ -166,8 +166,8 @@ def measured_traffic_per_unit(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("problems", "windows"), default="problems")
     ap.add_argument("--problems", type=int, default=512,
                     help="problems per GPU (mode problems) or in all (mode windows)")
