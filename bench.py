@@ -163,6 +163,44 @@ def measured_traffic_per_unit(kernel):
     return found
 
 
+def parity_on_fixture(dev, copies=192):
+    """Max-norm relative error of F and of the gradient column against the vectors recorded from
+    the reference for Lorenz-96 D = 40 (tests/golden/sys_l96_ut_d40.npz, Euler), evaluated by the
+    kernels the timed region runs: the recorded problem is replicated `copies` times so that
+    the library takes the fused backward scan + gradient kernel.  None without the fixture."""
+    import torch
+    from vgpa_amd import engine, _lib
+    path = os.path.join(ROOT, "tests", "golden", "sys_l96_ut_d40.npz")
+    try:
+        with np.load(path, allow_pickle=False) as z:
+            g = {k: z[k] for k in z.files}
+    except OSError:
+        return None
+    D, N = int(g["D"]), int(g["N"])
+    sde = dict(Sig=np.array(g["Sig"]), theta=float(g["theta"]) if g["theta"].ndim == 0 else np.array(g["theta"]),
+               Rig=np.array(g["Rig"]), D=D, N=N, H=np.array(g["H"]), obsX=np.array(g["obsX"]),
+               obsY=np.array(g["obsY"]), px0=dict(mu0=np.array(g["mu0"]), tau0=np.array(g["tau0"])),
+               dt=float(g["dt"]), ode_method="EULER")
+    Ab = np.asarray(g["Ab"], dtype=np.float64).reshape(-1)
+    A1, b1 = Ab[: N * D * D].reshape(N, D, D), Ab[N * D * D:].reshape(N, D)
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, np.array(g["m0"]), np.array(g["S0"]), P=copies)
+    A = torch.from_numpy(A1).to(dev).expand(copies, N, D, D).contiguous()
+    b = torch.from_numpy(b1).to(dev).expand(copies, N, D).contiguous()
+    st, gLA, gLb = engine.free_energy_and_gradient(prob, A, b)
+    F_ref, g_ref = float(g["EULER.F"]), np.asarray(g["EULER.grad"], dtype=np.float64).reshape(-1)
+    F_err = float((st.F - F_ref).abs().max().item()) / abs(F_ref)
+    got = torch.cat((gLA.reshape(copies, -1), gLb.reshape(copies, -1)), dim=1).cpu().numpy()
+    g_err = float(np.max(np.abs(got - g_ref[None, :])) / np.max(np.abs(g_ref)))
+    sflags = (_lib.SCAN_SYMMETRIC if prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D) else 0) | \
+             (_lib.SCAN_STATE_SYMMETRIC if prob.sym_fwd else 0)
+    fused = bool(_lib.lib.vgpa_bwd_scan_grad_is_fused(prob.method, copies, D, sflags,
+                                                      _lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0, 0, 0,
+                                                      prob.system))
+    return {"fixture": os.path.relpath(path, ROOT), "recorded_from": "the reference's varFreeEnergy + gradL_Ab",
+            "problems": copies, "N": N, "D": D, "fused_backward_kernel": fused,
+            "F_rel_err": F_err, "grad_rel_err": g_err, "tol": 1e-9, "ok": bool(F_err <= 1e-9 and g_err <= 1e-9)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,6 +397,9 @@ def main():
                               "sharding": f"time windows x{world}",
                               "collective": "all_reduce of (2 + 2 D) partial sums per problem; "
                                             "point-to-point scan boundary rows"}
+        # the same kernels against the vectors recorded from the reference (outside the timed region)
+        line["parity"] = parity_on_fixture(dev)
+        line["valid"] = bool(ok and (line["parity"] is None or line["parity"]["ok"]))
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
