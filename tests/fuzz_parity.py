@@ -143,6 +143,29 @@ def check(cfg, rng):
                 v = np.inf
             if v > worst:
                 worst, where = v, f"{k}[p={p}]"
+    if P == 1:
+        # the reference-signature entry points on host arrays (column or flat Ab, chosen at random)
+        from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+        from vgpa_amd.core.gradL_Ab import gradL_Ab
+        from vgpa_amd.dynamics import (sys_ornstein_uhlenbeck, sys_double_well, sys_lorenz_63, sys_lorenz_63_ut,
+                                       sys_lorenz_96_ut)
+        mod = dict(ou=sys_ornstein_uhlenbeck, dw=sys_double_well, l63=sys_lorenz_63, l63_ut=sys_lorenz_63_ut,
+                   l96_ut=sys_lorenz_96_ut)[system]
+        Ab = np.concatenate((cfg["A"][0].ravel(), cfg["b"][0].ravel()))
+        if rng.random() < 0.5:
+            Ab = Ab.reshape(-1, 1)
+        mParam = dict(m0=cfg["m0"], S0=cfg["S0"], fun=mod.energy_mode, sde_struct=dict(sde, checkGradf=False))
+        F = varFreeEnergy(Ab, mParam)
+        grad = gradL_Ab(Ab, mParam, bool(rng.random() < 0.3))
+        ref = orc.evaluate(system, Ab, cfg["m0"], cfg["S0"], sde)
+        errs = {"facade.F": abs(F - ref["F"]) / max(abs(ref["F"]), 1e-300) if isinstance(F, float) else np.inf,
+                "facade.grad": relerr(grad, ref["grad"]) if grad.shape == (Ab.size, 1) else np.inf,
+                "facade.mt": relerr(mParam["mt"], ref["m"]), "facade.St": relerr(mParam["St"], ref["S"]),
+                "facade.lamt": relerr(mParam["lamt"], ref["lam"]), "facade.Psit": relerr(mParam["Psit"], ref["Psi"])}
+        for k, v in errs.items():
+            v = v if np.isfinite(v) else np.inf
+            if v > worst:
+                worst, where = v, k
     return worst, where
 
 
