@@ -18,7 +18,7 @@ def short(name):
 # 1. kernel statistics of the bench command
 rows = list(csv.DictReader(open(os.path.join(PF, "kernel_stats.csv"))))
 with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu   "
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-parity   "
             "(1 MI355X, 512 problems, N=2002, 7 evaluations)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in rows:
@@ -27,7 +27,9 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
 
 def counters(sub):
     out = {}
-    for fn in glob.glob(os.path.join(PF, sub, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges every run's files into gpurun_out/: only the newest collection of this pass counts
+    files = sorted(glob.glob(os.path.join(PF, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for fn in files[-1:]:
         acc, disp = {}, {}
         for r in csv.DictReader(open(fn)):
             k = short(r["Kernel_Name"])
@@ -44,8 +46,8 @@ fe, wr = counters("fetch"), counters("write")
 units = 256 * 2002
 alg = {"fwd_euler_sym_mfma40_kernel": 26240, "esde_l96_ut_wave40_kernel<false>": 39688, "bwd_grad_euler_sym_mfma40_kernel": 66240}
 text = [f"# HBM traffic per launch from rocprofv3 PMC counters ({tag})",
-        "# commands (two separate passes): rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --problems 256",
-        "#                                 rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --problems 256",
+        "# commands (two separate passes): rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity --problems 256",
+        "#                                 rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity --problems 256",
         f"# workload: Lorenz-96 D=40 N=2002, 256 problems = {units} problem*timesteps per launch (averages over the launches of each kernel)",
         "# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane",
         "# coalesced streaming reads (128-byte requests tallied as 64), so reads are doubled.",
