@@ -9,7 +9,7 @@ observation terms, per-step energy kernel, time reductions, backward scan fused
 with the gradient assembly.  value = P_total * N * steps / time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode problems|windows]
-                  [--problems P] [--micro M] [--no-cpu] [--no-parity]
+                  [--problems P] [--micro M] [--backend nccl|gloo] [--no-cpu] [--no-parity]
 
 --mode problems (default): P problems PER GPU, sharded by problem across the ranks
   (vgpa_amd.batch.evaluate_problem_shard): no data-path collective, one all_gather of
@@ -211,6 +211,9 @@ def main():
                     help="problems per GPU (mode problems) or in all (mode windows)")
     ap.add_argument("--micro", type=int, default=None,
                     help="micro-batches of problems (mode windows); default 4, or 1 when there is one window")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for N > 1: nccl (RCCL, one GPU per rank) or gloo with the messages "
+                         "staged through the host (ranks may then share a GPU: a rehearsal on a one-GPU box)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the fixture check after the timed region (profiling runs: its small launches "
@@ -229,6 +232,8 @@ def main():
         cpu = cpu_baseline(D, dt)          # before the GPU is initialised
 
     import torch
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -237,13 +242,18 @@ def main():
     force_dist = world == 1 and os.environ.get("VGPA_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         import torch.distributed as dist
-        if force_dist and "MASTER_ADDR" not in os.environ:
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        elif force_dist and "MASTER_ADDR" not in os.environ:
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     from vgpa_amd import batch, engine, _lib
-    comm = batch.DistComm() if dist is not None else batch.SingleComm()
+    if dist is None:
+        comm = batch.SingleComm()
+    else:
+        comm = batch.HostStagedComm() if args.backend == "gloo" else batch.DistComm()
 
     events = {k: [] for k in ("fwd_scan", "esde", "bwd_scan_grad")}
 
@@ -321,7 +331,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     F, status = out
@@ -351,7 +361,8 @@ def main():
             line["config"] = {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
                                           f"{P} problems per GPU (theta grid), F + dL/dA, dL/db",
                               "problems_per_gpu": P, "N": N, "D": D, "sharding": f"problems x{world}",
-                              "collective": "all_gather of F" if world > 1 else "none (1 rank)"}
+                              "collective": "all_gather of F" if world > 1 else "none (1 rank)",
+                              "backend": args.backend if dist is not None else None}
             kernel_ms = {k: float(np.mean([a.elapsed_time(b_) for a, b_ in v])) for k, v in events.items()}
             esde_ms = kernel_ms["esde"]
             bytes_per_unit = 8 * (3 * D * D + 4 * D + 1)   # reads A, S, b, m; writes dEsde_dS, dEsde_dm, Ef, Esde_t
@@ -399,7 +410,8 @@ def main():
                               "problems": P, "micro_batches": len(ops), "N": N, "D": D,
                               "sharding": f"time windows x{world}",
                               "collective": "all_reduce of (2 + 2 D) partial sums per problem; "
-                                            "point-to-point scan boundary rows"}
+                                            "point-to-point scan boundary rows",
+                              "backend": args.backend if dist is not None else None}
         # the same kernels against the vectors recorded from the reference (outside the timed region)
         line["parity"] = None if args.no_parity else parity_on_fixture(dev)
         line["valid"] = bool(ok and (line["parity"] is None or line["parity"]["ok"]))

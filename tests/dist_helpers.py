@@ -135,7 +135,7 @@ def _init(rank, world, port):
     return dist
 
 
-def worker_time_sharded(rank, world, port, fixture, system, method, outdir):
+def worker_time_sharded(rank, world, port, fixture, system, method, outdir, comm_class="DistComm"):
     dist = _init(rank, world, port)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -144,7 +144,7 @@ def worker_time_sharded(rank, world, port, fixture, system, method, outdir):
         sde = sde_from_golden(g, method)
         m0, S0 = initial_moments(g)
         A, b = orc.unpack_Ab(g["Ab"], int(g["N"]), int(g["D"]))
-        res = run_time_sharded(system, sde, m0, S0, A, b, batch.DistComm())
+        res = run_time_sharded(system, sde, m0, S0, A, b, getattr(batch, comm_class)())
         np.savez(os.path.join(outdir, f"r{rank}.npz"), F=res.F.numpy(), gLA=res.gLA.numpy(), gLb=res.gLb.numpy(),
                  m=res.m.numpy(), lam=res.lam.numpy(), t0=res.window.t0, t1=res.window.t1,
                  dth=res.dth.numpy(), dSig=res.dSig.numpy())
@@ -152,10 +152,10 @@ def worker_time_sharded(rank, world, port, fixture, system, method, outdir):
         dist.destroy_process_group()
 
 
-def worker_problem_shard(rank, world, port, P_total, outdir):
+def worker_problem_shard(rank, world, port, P_total, outdir, comm_class="DistComm"):
     dist = _init(rank, world, port)
     try:
-        comm = batch.DistComm()
+        comm = getattr(batch, comm_class)()
 
         def evaluate(lo, hi):
             # a stand-in evaluation whose value identifies the problem
@@ -164,5 +164,37 @@ def worker_problem_shard(rank, world, port, P_total, outdir):
 
         F_all, extras, (lo, hi) = batch.evaluate_problem_shard(evaluate, P_total, comm)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), F=F_all.numpy(), lo=lo, hi=hi, count=extras["count"])
+    finally:
+        dist.destroy_process_group()
+
+
+def worker_device_windows(rank, world, port, fixture, method, micro, outdir):
+    """Two or more PROCESSES that share cuda:0: DeviceWindowOps (the HIP kernels) on each rank's window,
+    messages staged through the host over gloo."""
+    dist = _init(rank, world, port)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import load_golden, sde_from_golden, initial_moments
+        from vgpa_amd import engine, _lib
+        torch.cuda.set_device(0)
+        g = load_golden(fixture + ".npz")
+        sde = sde_from_golden(g, method)
+        m0, S0 = initial_moments(g)
+        N, D, P = int(g["N"]), int(g["D"]), 4
+        An, bn = orc.unpack_Ab(g["Ab"], N, D)
+        rng = np.random.default_rng(3)                     # the same problems on every rank
+        A = engine.to_dev(An[None] + 0.05 * rng.standard_normal((P, N, D, D)))
+        b = engine.to_dev(bn[None] + 0.5 * rng.standard_normal((P, N, D)))
+        win = batch.time_window(N, rank, world)
+        sl = win.local_slice()
+        ops = []
+        for c in range(micro):
+            lo, hi = batch.shard_bounds(P, c, micro)
+            ops.append(batch.DeviceWindowOps(_lib.SYS_L96_UT, sde, m0, S0, win, A[lo:hi, sl].contiguous(),
+                                             b[lo:hi, sl].contiguous(), P=hi - lo))
+        res = batch.free_energy_time_sharded(ops, batch.HostStagedComm())
+        cat = lambda k, dim=0: torch.cat([getattr(r, k) for r in res], dim=dim).cpu().numpy()   # noqa: E731
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), F=cat("F"), gLA=cat("gLA"), gLb=cat("gLb"), dth=cat("dth"),
+                 dSig=cat("dSig"), t0=win.t0, t1=win.t1)
     finally:
         dist.destroy_process_group()

@@ -142,6 +142,26 @@ def test_problem_shard_gloo_world2(tmp_path):
     assert bounds == [(0, 3), (3, 5)]
 
 
+def test_host_staged_communicator_gloo_world2(tmp_path):
+    """batch.HostStagedComm (device tensors through host copies; here the tensors are host tensors
+    already) carries the same messages as DistComm: time windows and the gather of F."""
+    import torch.multiprocessing as mp
+    (tmp_path / "w").mkdir()
+    (tmp_path / "p").mkdir()
+    mp.spawn(dh.worker_time_sharded, args=(2, _free_port(), "sys_l63_ut", "l63_ut", "HEUN", str(tmp_path / "w"),
+                                           "HostStagedComm"), nprocs=2, join=True)
+    parts = [np.load(tmp_path / "w" / f"r{r}.npz") for r in range(2)]
+    g = load_golden("sys_l63_ut.npz")
+    sde = sde_from_golden(g, "HEUN")
+    m0, S0 = initial_moments(g)
+    ref = orc.evaluate("l63_ut", g["Ab"], m0, S0, sde)
+    _check_against_unsharded(parts, ref, int(g["N"]), int(g["D"]))
+    mp.spawn(dh.worker_problem_shard, args=(2, _free_port(), 5, str(tmp_path / "p"), "HostStagedComm"), nprocs=2, join=True)
+    want = np.array([1000.0 + 3.0 * p for p in range(5)])
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / "p" / f"r{r}.npz")["F"], want)
+
+
 def test_gather_problem_values_single_rank_is_identity():
     x = torch.arange(4, dtype=torch.float64)
     assert batch.gather_problem_values(x, 4, batch.SingleComm()) is x

@@ -131,3 +131,38 @@ def test_bwd_scan_terminal_state_vs_oracle(D, method):
                                Psi_last=engine.to_dev(PsiT.reshape((1,) + PsiT.shape if D > 1 else (1,))))
     assert relerr(lam.cpu().numpy().reshape(-1), lr.reshape(-1)) <= TOL
     assert relerr(Psi.cpu().numpy().reshape(-1), Pr.reshape(-1)) <= TOL
+
+
+def test_time_windows_across_processes_sharing_the_gpu(tmp_path):
+    """Two processes, one window each, both on cuda:0: the device ops of every rank with a real
+    torch.distributed process group between them (gloo, messages staged through the host by
+    batch.HostStagedComm) against the one-call device evaluation in this process."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    import dist_helpers
+    from vgpa_amd import engine, _lib
+    g = load_golden("sys_l96_ut_d40.npz")
+    sde = sde_from_golden(g, "EULER")
+    m0, S0 = initial_moments(g)
+    N, D, P, world = int(g["N"]), 40, 4, 2
+    An, bn = orc.unpack_Ab(g["Ab"], N, D)
+    rng = np.random.default_rng(3)
+    A = engine.to_dev(An[None] + 0.05 * rng.standard_normal((P, N, D, D)))
+    b = engine.to_dev(bn[None] + 0.5 * rng.standard_normal((P, N, D)))
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=P)
+    st = engine.free_energy(prob, A, b, want_edf=False, want_hyper=True)
+    gLA, gLb = engine.gradient(prob, A, b, st)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(dist_helpers.worker_device_windows, args=(world, port, "sys_l96_ut_d40", "EULER", 2, str(tmp_path)),
+             nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert relerr(parts[r]["F"], st.F.cpu().numpy()) <= 1e-12
+        assert relerr(parts[r]["dth"], st.dth.cpu().numpy()) <= 1e-12
+        assert relerr(parts[r]["dSig"], st.dSig.cpu().numpy()) <= 1e-12
+    assert [int(parts[r]["t0"]) for r in range(world)] == [0, int(parts[0]["t1"])]
+    assert relerr(np.concatenate([parts[r]["gLA"] for r in range(world)], axis=1), gLA.cpu().numpy()) <= 1e-12
+    assert relerr(np.concatenate([parts[r]["gLb"] for r in range(world)], axis=1), gLb.cpu().numpy()) <= 1e-12

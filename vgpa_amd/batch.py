@@ -133,6 +133,36 @@ class DistComm:
         return out
 
 
+class HostStagedComm(DistComm):
+    """DistComm for a process group whose backend moves host memory only (gloo): device tensors
+    travel through host copies.  For ranks that share one GPU, or a node without a working RCCL:
+    the messages are boundary rows and a few numbers per problem, so the staging cost is small."""
+
+    def send(self, dst, tensors):
+        self._pending = [(w, b) for w, b in self._pending if not w.is_completed()]
+        buf = torch.cat([t.reshape(-1) for t in tensors]).cpu().contiguous()
+        self._pending.append((self._dist.isend(buf, self._global(dst), group=self._group), buf))
+
+    def recv(self, src, shapes, device):
+        sizes = [int(np.prod(s)) for s in shapes]
+        buf = torch.empty(sum(sizes), dtype=torch.float64)
+        self._dist.recv(buf, self._global(src), group=self._group)
+        buf = buf.to(device)
+        return [c.reshape(s) for c, s in zip(torch.split(buf, sizes), shapes)]
+
+    def all_reduce_sum(self, t):
+        h = t.detach().cpu()
+        self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self._group)
+        t.copy_(h)
+        return t
+
+    def all_gather(self, t):
+        h = t.detach().cpu().contiguous()
+        out = [torch.empty_like(h) for _ in range(self.world)]
+        self._dist.all_gather(out, h, group=self._group)
+        return [o.to(t.device) for o in out]
+
+
 class SingleComm:
     """World of one: no messages, collectives are the identity."""
     rank, world = 0, 1
