@@ -7,7 +7,7 @@ operators, per-problem drift parameters -- evaluates F, the gradient and every i
 engine.free_energy_and_gradient (and the two-call path engine.free_energy + engine.gradient), and
 compares a few problems of each batch with oracle.evaluate at 1e-9 max-norm relative.
 
-  python tests/fuzz_parity.py [seconds] [first_seed]
+  python tests/fuzz_parity.py [seconds] [first_seed] [long]
 
 Prints one line per configuration and a summary; exit status 1 when any comparison failed.
 tests/test_gpu_fuzz.py runs a fixed number of seeds of it through ``sweep``.
@@ -104,6 +104,31 @@ def draw(rng):
         else:
             thetas = None
     return dict(system=str(system), method=method, D=D, P=P, N=N, sde=sde, m0=m0, S0=S0, A=A, b=b, thetas=thetas)
+
+
+def draw_long(rng):
+    """Lorenz-96 at the matrix-core dimensions with long time axes (the scans' prefetch rings and chunk
+    boundaries), every integrator, both sides of the fused-kernel threshold."""
+    cfg = None
+    while cfg is None or cfg["system"] != "l96_ut":
+        cfg = draw(rng)
+    D = int(rng.choice((16, 40, 40, 40)))
+    P = int(rng.choice((1, 2, 161, 163)))
+    N = int(rng.choice((63, 64, 65, 127, 128, 129, 255, 257, 300, 511, 513, 1000)))
+    if P > 100:
+        N = min(N, 257)
+    sde = dict(cfg["sde"], D=D, N=N)
+    obsX = np.unique(np.concatenate((rng.choice(N, size=5, replace=False), [N - 1] if rng.random() < 0.5 else [N // 2])))
+    Sig = spd(rng, D, 3.0, 5.0, False)
+    mu0 = rng.standard_normal(D)
+    sde.update(Sig=Sig, Rig=np.eye(D), H=np.eye(D), obsX=obsX, obsY=3.0 * rng.standard_normal((obsX.size, D)),
+               px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)), theta=8.0)
+    a0 = 0.5 * float(np.mean(np.diag(Sig))) / 0.25
+    A = a0 * np.eye(D)[None, None] + 0.1 * rng.standard_normal((P, N, D, D))
+    b = 5.0 * rng.standard_normal((P, N, D))
+    thetas = 8.0 * (1.0 + 0.05 * rng.standard_normal((P, 1))) if P > 1 else None
+    return dict(system="l96_ut", method=cfg["method"], D=D, P=P, N=N, sde=sde, m0=mu0 + 0.1 * rng.standard_normal(D),
+                S0=spd(rng, D, 0.2, 0.3, rng.random() < 0.5), A=A, b=b, thetas=thetas)
 
 
 def check(cfg, rng):
@@ -220,14 +245,15 @@ def sweep_energy(first_seed, count, verbose=True):
     return failures, worst_all
 
 
-def sweep(first_seed, count=None, seconds=None, verbose=True):
+def sweep(first_seed, count=None, seconds=None, verbose=True, long_axes=False):
     """Configurations first_seed, first_seed + 1, ...: `count` of them, or as many as fit in `seconds`.
+    ``long_axes``: draw_long instead of draw.
     Returns (configurations, skipped, failures, worst error); failures is a list of report lines."""
     t0, n, skipped, worst_all, failures = time.time(), 0, 0, 0.0, []
     seed = first_seed
     while (count is None or n < count) and (seconds is None or time.time() - t0 < seconds):
         rng = np.random.default_rng(seed)
-        cfg = draw(rng)
+        cfg = draw_long(rng) if long_axes else draw(rng)
         tag = (f"seed {seed}: {cfg['system']:7s} {cfg['method']:5s} D={cfg['D']:2d} N={cfg['N']:3d} P={cfg['P']:3d} "
                f"obs={[int(i) for i in cfg['sde']['obsX']]}")
         try:
@@ -258,6 +284,11 @@ def sweep(first_seed, count=None, seconds=None, verbose=True):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "long":
+        n, skipped, failures, worst_all = sweep(seed, seconds=budget, long_axes=True)
+        print(f"{n} long-axis configurations, {skipped} skipped, {len(failures)} failed, worst error {worst_all:.2e} "
+              f"(tolerance {TOL:g})", flush=True)
+        sys.exit(1 if failures else 0)
     e_fail, e_worst = sweep_energy(seed, 200)
     print(f"200 energy_mode configurations with non-positive-definite steps, {len(e_fail)} failed, worst error {e_worst:.2e}",
           flush=True)
