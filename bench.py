@@ -226,6 +226,9 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     D, N, dt, P = 40, 2002, 0.005, args.problems
+    # the host driver of this pool shares device memory between processes through dmabuf only (RCCL's
+    # hipIpcGetMemHandle fails otherwise); normally exported already, set before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     cpu = None
     if not args.no_cpu and world == 1 and rank == 0:
