@@ -204,7 +204,7 @@ def parity_on_fixture(dev, copies=192):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("problems", "windows"), default="problems")
     ap.add_argument("--problems", type=int, default=512,
