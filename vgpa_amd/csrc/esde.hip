@@ -763,7 +763,13 @@ void launch_l96_tiled_h(const EsdeArgs& a, size_t total, hipStream_t st) {
 // dimension holds are launched in slices of the problem axis.
 void launch_l96_wave40(const EsdeArgs& a, hipStream_t st) {
     constexpr int MAXP = 65535;
+#ifdef VGPA_EXPERIMENT_LDS_PAD
+    // occupancy experiments: a larger LDS request per workgroup lowers the number of resident wavefronts
+    static const size_t pad = getenv("VGPA_ESDE_LDS_PAD") ? (size_t)atol(getenv("VGPA_ESDE_LDS_PAD")) : 0;
+    const size_t lds = L96Wave::WG_LDS_BYTES + pad;
+#else
     const size_t lds = L96Wave::WG_LDS_BYTES;
+#endif
     const size_t N = (size_t)a.N, D = 40, DD = 1600;
     for (int p0 = 0; p0 < a.P; p0 += MAXP) {
         EsdeArgs s = a;
