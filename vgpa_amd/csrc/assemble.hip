@@ -80,6 +80,52 @@ obs_terms_nd_kernel(int N, int D, int M, const double* __restrict__ m, const dou
     if (l == 0) work[(size_t)p * M + n] = e_l;
 }
 
+// The same for D = 2, 3 with one LANE per (observation, problem): a wavefront per 3-vector leaves 61 lanes
+// idle and a grid of thousands of problems costs hundreds of thousands of one-wavefront workgroups.  Same
+// products and sums in the same order (the sum over components in the order of the shuffle tree above:
+// (e_0 + e_2) + e_1), so the results are the same bits.
+template <int D>
+__global__ void __launch_bounds__(256)
+obs_terms_small_kernel(int P, int N, int M, const double* __restrict__ m, const double* __restrict__ S,
+                       const int* __restrict__ obs_idx, const double* __restrict__ obsY, int obsY_stride,
+                       const double* __restrict__ H, const double* __restrict__ Ri, const double* __restrict__ Qi,
+                       double* __restrict__ work, double* __restrict__ dEobs_dm) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)P * M) return;
+    const int p = (int)(q / M), n = (int)(q % M);
+    const double* Y = obsY + (size_t)p * obsY_stride + (size_t)n * D;
+    const int tn = obs_idx[n];
+    const double* mt = m + ((size_t)p * N + tn) * D;
+    const double* St = S + ((size_t)p * N + tn) * D * D;
+    double Wv[D], Tv[D], e[D];
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+        double hm = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) hm = fma(mt[i], H[i * D + l], hm);
+        Wv[l] = Y[l] - hm;
+    }
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+        double z = 0.0, t = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            z = fma(Wv[j], Qi[l * D + j], z);
+            t = fma(Ri[l * D + j], Wv[j], t);
+        }
+        Tv[l] = t;
+        e[l] = z * z + Ri[l * D + l] * St[l * D + l];
+    }
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+        double gsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) gsum = fma(H[k * D + l], Tv[k], gsum);
+        dEobs_dm[((size_t)p * N + tn) * D + l] = -gsum;
+    }
+    work[q] = (D == 3) ? (e[0] + e[D - 1]) + e[1] : e[0] + e[1];
+}
+
 // jumpS = 0.5 H' Ri H (one workgroup; the D x D product Ri H goes through LDS).
 __global__ void __launch_bounds__(256)
 obs_jump_kernel(int D, const double* __restrict__ H, const double* __restrict__ Ri, double* __restrict__ jumpS) {
@@ -557,9 +603,18 @@ int obs_terms_impl(const char* who, int P, int N, int D, int M, int d, const dou
                            obsY_stride, H, Ri, logconst, Eobs, dEobs_dm, jumpS);
     } else {
         const size_t lds = sizeof(double) * 2 * D;
-        if (M > 0)
+        if (M > 0 && (D == 2 || D == 3)) {
+            const unsigned grid = (unsigned)(((size_t)P * M + 255) / 256);
+            if (D == 2)
+                hipLaunchKernelGGL(obs_terms_small_kernel<2>, dim3(grid), dim3(256), 0, st, P, N, M, m, S, obs_idx, obsY,
+                                   obsY_stride, H, Ri, Qi, work, dEobs_dm);
+            else
+                hipLaunchKernelGGL(obs_terms_small_kernel<3>, dim3(grid), dim3(256), 0, st, P, N, M, m, S, obs_idx, obsY,
+                                   obsY_stride, H, Ri, Qi, work, dEobs_dm);
+        } else if (M > 0) {
             hipLaunchKernelGGL(obs_terms_nd_kernel, dim3(M, P), dim3(64), lds, st, N, D, M, m, S, obs_idx, obsY,
                                obsY_stride, H, Ri, Qi, work, dEobs_dm);
+        }
         if (jumpS)
             hipLaunchKernelGGL(obs_jump_kernel, dim3(1), dim3(256), sizeof(double) * D * D, st, D, H, Ri, jumpS);
         hipLaunchKernelGGL(obs_finish_kernel, dim3((P + 63) / 64), dim3(64), 0, st, P, M, work, logconst, Eobs);

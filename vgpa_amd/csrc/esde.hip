@@ -91,16 +91,85 @@ struct L63In {
     double iS[3];
 };
 
-__device__ inline void l63_load(const EsdeArgs& a, size_t e, int p, L63In& x) {
+// The 64 units of a wavefront are contiguous in every (P, N, RD) array.  When each lane reads its own RD
+// numbers an instruction touches up to 36 cache lines; here the wavefront moves its 64 * RD doubles with
+// 16-byte accesses of consecutive lanes and each lane picks its numbers out of LDS (odd stride RD: no
+// bank conflicts), and the per-unit results go back the same way.  One buffer of 64 * 9 doubles per
+// wavefront, used for one array at a time.  `wave_ok`: all 64 units of the wavefront exist.
+struct L63Stage {
+    static constexpr int BUF = 64 * 9;
+    static __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+    static __device__ __forceinline__ bool aligned(const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; }
+    // v[0 .. RD) = src[(e0 + lane) * RD + ...], e0 = first unit of the wavefront
+    template <int RD>
+    static __device__ __forceinline__ void in(const double* __restrict__ src, size_t e0, int lane, double* buf, double (&v)[RD]) {
+        constexpr int PIECES = 64 * RD / 2;
+        const double2* s2 = reinterpret_cast<const double2*>(src + e0 * RD);
+        double2* b2 = reinterpret_cast<double2*>(buf);
+#pragma unroll
+        for (int k = 0; k * 64 < PIECES; ++k)
+            if (k * 64 + lane < PIECES) b2[k * 64 + lane] = s2[k * 64 + lane];
+        fence();
+#pragma unroll
+        for (int j = 0; j < RD; ++j) v[j] = buf[lane * RD + j];
+        fence();
+    }
+    template <int RD>
+    static __device__ __forceinline__ void out(double* __restrict__ dst, size_t e0, int lane, double* buf, const double (&v)[RD]) {
+        constexpr int PIECES = 64 * RD / 2;
+#pragma unroll
+        for (int j = 0; j < RD; ++j) buf[lane * RD + j] = v[j];
+        fence();
+        double2* d2 = reinterpret_cast<double2*>(dst + e0 * RD);
+        const double2* b2 = reinterpret_cast<const double2*>(buf);
+#pragma unroll
+        for (int k = 0; k * 64 < PIECES; ++k)
+            if (k * 64 + lane < PIECES) d2[k * 64 + lane] = b2[k * 64 + lane];
+        fence();
+    }
+    // one per-unit array of RD doubles: staged when the wavefront is whole and the block is 16-byte aligned
+    template <int RD>
+    static __device__ __forceinline__ void load(const double* __restrict__ src, size_t e, int lane, bool wave_ok, double* buf,
+                                                double (&v)[RD]) {
+        if (wave_ok && aligned(src + (e - lane) * RD)) {
+            in<RD>(src, e - lane, lane, buf, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < RD; ++j) v[j] = src[e * RD + j];
+        }
+    }
+    template <int RD>
+    static __device__ __forceinline__ void store(double* __restrict__ dst, size_t e, int lane, bool wave_ok, double* buf,
+                                                 const double (&v)[RD]) {
+        if (wave_ok && aligned(dst + (e - lane) * RD)) {
+            out<RD>(dst, e - lane, lane, buf, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < RD; ++j) dst[e * RD + j] = v[j];
+        }
+    }
+};
+
+// per-wavefront staging context of the Lorenz-63 kernels
+struct L63Io {
+    double* buf;
+    int lane;
+    bool wave_ok;
+};
+
+__device__ inline void l63_load(const EsdeArgs& a, size_t e, int p, L63In& x, const L63Io& io) {
+    double Af[9], Sf[9];
+    L63Stage::load<9>(a.A, e, io.lane, io.wave_ok, io.buf, Af);
+    L63Stage::load<9>(a.S, e, io.lane, io.wave_ok, io.buf, Sf);
+    L63Stage::load<3>(a.b, e, io.lane, io.wave_ok, io.buf, x.b);
+    L63Stage::load<3>(a.m, e, io.lane, io.wave_ok, io.buf, x.m);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        x.b[i] = a.b[e * 3 + i];
-        x.m[i] = a.m[e * 3 + i];
         x.iS[i] = a.sig_inv_diag[(size_t)p * a.sig_stride + i];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            x.A[i][j] = a.A[e * 9 + i * 3 + j];
-            x.S[i][j] = a.S[e * 9 + i * 3 + j];
+            x.A[i][j] = Af[i * 3 + j];
+            x.S[i][j] = Sf[i * 3 + j];
         }
     }
     const double* th = a.theta + (size_t)p * a.theta_stride;
@@ -111,16 +180,13 @@ __device__ inline void l63_load(const EsdeArgs& a, size_t e, int p, L63In& x) {
 
 // <f>, <df/dx> (dynamics/sys_lorenz_63.py:222-227) and <(f-g)' df/dtheta>
 // (Efg_drift_theta, dynamics/sys_lorenz_63.py:491-549).
-__device__ inline void l63_common_outputs(const EsdeArgs& a, size_t e, const L63In& x) {
+__device__ inline void l63_common_outputs(const EsdeArgs& a, size_t e, const L63In& x, const L63Io& io) {
     const double mx = x.m[0], my = x.m[1], mz = x.m[2];
-    a.Ef[e * 3 + 0] = x.vS * (my - mx);
-    a.Ef[e * 3 + 1] = x.vR * mx - my - x.S[2][0] - mx * mz;
-    a.Ef[e * 3 + 2] = x.S[1][0] + mx * my - x.vB * mz;
+    const double Ef[3] = {x.vS * (my - mx), x.vR * mx - my - x.S[2][0] - mx * mz, x.S[1][0] + mx * my - x.vB * mz};
+    L63Stage::store<3>(a.Ef, e, io.lane, io.wave_ok, io.buf, Ef);
     if (a.Edf) {
-        double* E = a.Edf + e * 9;
-        E[0] = -x.vS; E[1] = x.vS; E[2] = 0.0;
-        E[3] = x.vR - mz; E[4] = -1.0; E[5] = -mx;
-        E[6] = my; E[7] = mx; E[8] = -x.vB;
+        const double E[9] = {-x.vS, x.vS, 0.0, x.vR - mz, -1.0, -mx, my, mx, -x.vB};
+        L63Stage::store<9>(a.Edf, e, io.lane, io.wave_ok, io.buf, E);
     }
     if (a.dth_t) {
         const double Sxx = x.S[0][0], Sxy = x.S[0][1], Sxz = x.S[0][2];
@@ -132,10 +198,11 @@ __device__ inline void l63_common_outputs(const EsdeArgs& a, size_t e, const L63
         const double A11 = x.A[0][0], A12 = x.A[0][1], A13 = x.A[0][2];
         const double A21 = x.A[1][0], A22 = x.A[1][1], A23 = x.A[1][2];
         const double A31 = x.A[2][0], A32 = x.A[2][1], A33 = x.A[2][2];
-        a.dth_t[e * 3 + 0] = Eyy * (x.vS + A12) + Exx * (x.vS - A11) + Exy * (A11 - 2 * x.vS - A12) +
-                             A13 * (Eyz - Exz) + x.b[0] * (mx - my);
-        a.dth_t[e * 3 + 1] = x.vR * Exx - Exy - Exxz + A21 * Exx + A22 * Exy + A23 * Exz - x.b[1] * mx;
-        a.dth_t[e * 3 + 2] = -Exyz + x.vB * Ezz - A31 * Exz - A32 * Eyz - A33 * Ezz + x.b[2] * mz;
+        const double dth[3] = {Eyy * (x.vS + A12) + Exx * (x.vS - A11) + Exy * (A11 - 2 * x.vS - A12) +
+                                   A13 * (Eyz - Exz) + x.b[0] * (mx - my),
+                               x.vR * Exx - Exy - Exxz + A21 * Exx + A22 * Exy + A23 * Exz - x.b[1] * mx,
+                               -Exyz + x.vB * Ezz - A31 * Exz - A32 * Eyz - A33 * Ezz + x.b[2] * mz};
+        L63Stage::store<3>(a.dth_t, e, io.lane, io.wave_ok, io.buf, dth);
     }
 }
 
@@ -144,13 +211,16 @@ __device__ inline void l63_common_outputs(const EsdeArgs& a, size_t e, const L63
 // Energy_dm_dS, dynamics/sys_lorenz_63.py:247-488.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) esde_l63_kernel(EsdeArgs a) {
+    __shared__ __align__(16) double stage[4][L63Stage::BUF];
     const size_t total = (size_t)a.P * a.N;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e / a.N);
+    const int lane = threadIdx.x & 63;
+    const L63Io io{stage[threadIdx.x >> 6], lane, (e - lane) + 64 <= total};
     L63In x;
-    l63_load(a, e, p, x);
-    l63_common_outputs(a, e, x);
+    l63_load(a, e, p, x, io);
+    l63_common_outputs(a, e, x, io);
     const double vS = x.vS, vR = x.vR, vB = x.vB;
     const double mx = x.m[0], my = x.m[1], mz = x.m[2];
     const double Sxx = x.S[0][0], Sxy = x.S[0][1], Sxz = x.S[0][2];
@@ -183,9 +253,8 @@ __global__ void __launch_bounds__(256) esde_l63_kernel(EsdeArgs a) {
     const double iSx = x.iS[0], iSy = x.iS[1], iSz = x.iS[2];
     a.Esde_t[e] = 0.5 * (iSx * EX + iSy * EY + iSz * EZ);
     if (a.dSig_t) {
-        a.dSig_t[e * 3 + 0] = EX;
-        a.dSig_t[e * 3 + 1] = EY;
-        a.dSig_t[e * 3 + 2] = EZ;
+        const double EXYZ[3] = {EX, EY, EZ};
+        L63Stage::store<3>(a.dSig_t, e, io.lane, io.wave_ok, io.buf, EXYZ);
     }
     // moment derivatives w.r.t. the mean (:337-392); those equal to 1 are folded in
     const double dExx_dmx = 2 * mx, dExy_dmx = my, dExz_dmx = mz;
@@ -221,9 +290,9 @@ __global__ void __launch_bounds__(256) esde_l63_kernel(EsdeArgs a) {
                              dEyz_dmz * (A22 * A23 - A23) - A23 * (dExzz_dmz + b2));
     const double dmz3 = dEzz_dmz * (vB * vB + A33 * A33) +
                         2 * ((A33 - vB) * (dExyz_dmz + dExz_dmz * A31 + dEyz_dmz * A32 - b3) - vB * A33 * dEzz_dmz);
-    a.dEdm[e * 3 + 0] = 0.5 * (dmx1 * iSx + dmx2 * iSy + dmx3 * iSz);
-    a.dEdm[e * 3 + 1] = 0.5 * (dmy1 * iSx + dmy2 * iSy + dmy3 * iSz);
-    a.dEdm[e * 3 + 2] = 0.5 * (dmz1 * iSx + dmz2 * iSy + dmz3 * iSz);
+    const double dEdm[3] = {0.5 * (dmx1 * iSx + dmx2 * iSy + dmx3 * iSz), 0.5 * (dmy1 * iSx + dmy2 * iSy + dmy3 * iSz),
+                            0.5 * (dmz1 * iSx + dmz2 * iSy + dmz3 * iSz)};
+    L63Stage::store<3>(a.dEdm, e, io.lane, io.wave_ok, io.buf, dEdm);
     // moment derivatives w.r.t. the covariance (:376-400) and dEsde/dS (:449-486)
     const double dExxy_dSxx = my, dExxz_dSxx = mz;
     const double dExxy_dSxy = 2 * mx, dExyy_dSxy = 2 * my, dExyz_dSxy = mz;
@@ -247,10 +316,9 @@ __global__ void __launch_bounds__(256) esde_l63_kernel(EsdeArgs a) {
                         iSz * 2 * (dExyz_dSyz * (A33 - vB) + (A33 - vB) * A32);
     const double dSzz = iSx * (A13 * A13) + iSy * (dExxzz_dSzz + (A23 * A23) - 2 * A23 * dExzz_dSzz) +
                         iSz * ((vB - A33) * (vB - A33));
-    double* G = a.dEdS + e * 9;
-    G[0] = 0.5 * dSxx; G[1] = 0.5 * dSxy; G[2] = 0.5 * dSxz;
-    G[3] = 0.5 * dSxy; G[4] = 0.5 * dSyy; G[5] = 0.5 * dSyz;
-    G[6] = 0.5 * dSxz; G[7] = 0.5 * dSyz; G[8] = 0.5 * dSzz;
+    const double G[9] = {0.5 * dSxx, 0.5 * dSxy, 0.5 * dSxz, 0.5 * dSxy, 0.5 * dSyy, 0.5 * dSyz,
+                         0.5 * dSxz, 0.5 * dSyz, 0.5 * dSzz};
+    L63Stage::store<9>(a.dEdS, e, io.lane, io.wave_ok, io.buf, G);
 }
 
 // ---------------------------------------------------------------------------
@@ -261,13 +329,16 @@ __global__ void __launch_bounds__(256) esde_l63_kernel(EsdeArgs a) {
 // dynamics/sys_lorenz_63_ut.py:218-255.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) esde_l63_ut_kernel(EsdeArgs a) {
+    __shared__ __align__(16) double stage[4][L63Stage::BUF];
     const size_t total = (size_t)a.P * a.N;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e / a.N);
+    const int lane = threadIdx.x & 63;
+    const L63Io io{stage[threadIdx.x >> 6], lane, (e - lane) + 64 <= total};
     L63In x;
-    l63_load(a, e, p, x);
-    l63_common_outputs(a, e, x);
+    l63_load(a, e, p, x, io);
+    l63_common_outputs(a, e, x, io);
     constexpr int D = 3;
     const double kappa = 1.05 * D;
     const double c2 = D + kappa;
@@ -368,17 +439,17 @@ __global__ void __launch_bounds__(256) esde_l63_ut_kernel(EsdeArgs a) {
     }
     const double Esde = 0.5 * (x.iS[0] * mbar[0] + x.iS[1] * mbar[1] + x.iS[2] * mbar[2]);
     a.Esde_t[e] = Esde;
-    if (a.dSig_t) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) a.dSig_t[e * 3 + r] = mbar[r];
-    }
+    if (a.dSig_t) L63Stage::store<3>(a.dSig_t, e, io.lane, io.wave_ok, io.buf, mbar);
+    double dEdm[3], dEdS[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const double sim = Si[r][0] * x.m[0] + Si[r][1] * x.m[1] + Si[r][2] * x.m[2];
-        a.dEdm[e * 3 + r] = dm[r] - Esde * sim;
+        dEdm[r] = dm[r] - Esde * sim;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.dEdS[e * 9 + r * 3 + c] = 0.5 * (dS[r][c] - Esde * Si[r][c]);
+        for (int c = 0; c < 3; ++c) dEdS[r * 3 + c] = 0.5 * (dS[r][c] - Esde * Si[r][c]);
     }
+    L63Stage::store<3>(a.dEdm, e, io.lane, io.wave_ok, io.buf, dEdm);
+    L63Stage::store<9>(a.dEdS, e, io.lane, io.wave_ok, io.buf, dEdS);
     if (a.status) a.status[e] = st;
 }
 
