@@ -650,3 +650,31 @@ def test_small_dimension_scans_staged_through_lds_vs_oracle(D, N, P, method):
     # a problem gives the same bits alone as inside a batch
     m2, S2 = engine.fwd_scan(mid, d(A[-1:]), d(b[-1:]), d(m0[-1:]), d(S0[-1:]), d(Sig), dt, symmetric=False)
     assert torch.equal(S2[0], S1[-1]) and torch.equal(m2[0], m1[-1])
+
+
+@pytest.mark.parametrize("system", ["SYS_L63", "SYS_L63_UT"])
+def test_lorenz63_energy_on_views_that_are_not_16_byte_aligned(system):
+    """The Lorenz-63 kernels move the per-unit arrays with 16-byte accesses when a wavefront's block is
+    aligned and with per-lane accesses otherwise: a batch that starts one (odd-sized) problem into a larger
+    allocation must give the bits of the same batch in allocations of its own; the last wavefront of the
+    grid is a partial one (195 units)."""
+    import torch
+    from vgpa_amd import engine, _lib
+    rng = np.random.default_rng(63)
+    P, N, D = 4, 65, 3
+    A = engine.to_dev(20.0 * np.eye(D)[None, None] + 0.3 * rng.standard_normal((P, N, D, D)))
+    b = engine.to_dev(3.0 * rng.standard_normal((P, N, D)))
+    m = engine.to_dev(2.0 * rng.standard_normal((P, N, D)))
+    X = rng.standard_normal((P, N, D, D))
+    S = engine.to_dev(0.3 * np.eye(D)[None, None] + 0.1 * X @ np.swapaxes(X, -1, -2))
+    sid = engine.to_dev(1.0 / (8.0 + rng.random(D)))
+    theta = engine.to_dev(np.array([10.0, 28.0, 8.0 / 3.0]))
+    sys_id = getattr(_lib, system)
+    views = [t[1:] for t in (A, b, m, S)]
+    assert views[0].data_ptr() % 16 == 8 and views[1].data_ptr() % 16 == 8
+    got = engine.esde(sys_id, *views, sid, theta, True, True)
+    ref = engine.esde(sys_id, *[t.clone() for t in views], sid, theta, True, True)
+    full = engine.esde(sys_id, A, b, m, S, sid, theta, True, True)
+    for k in ("Esde_t", "Ef", "Edf", "dEdm", "dEdS", "dth_t", "dSig_t"):
+        assert torch.equal(got[k], ref[k]), k
+        assert torch.equal(got[k], full[k][1:]), k
