@@ -114,6 +114,32 @@ struct L63Stage {
         for (int j = 0; j < RD; ++j) v[j] = buf[lane * RD + j];
         fence();
     }
+    // the two halves of `in`: the wavefront's pieces into registers (no wait), and later through LDS
+    template <int RD>
+    static __device__ __forceinline__ void fetch(const double* __restrict__ src, size_t e0, int lane,
+                                                 double (&pre)[2 * ((64 * RD / 2 + 63) / 64)]) {
+        constexpr int PIECES = 64 * RD / 2, NI = (PIECES + 63) / 64;
+        const double2* s2 = reinterpret_cast<const double2*>(src + e0 * RD);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const double2 t = s2[min(k * 64 + lane, PIECES - 1)];
+            pre[2 * k] = t.x;
+            pre[2 * k + 1] = t.y;
+        }
+    }
+    template <int RD>
+    static __device__ __forceinline__ void scatter(const double (&pre)[2 * ((64 * RD / 2 + 63) / 64)], int lane, double* buf,
+                                                   double (&v)[RD]) {
+        constexpr int PIECES = 64 * RD / 2, NI = (PIECES + 63) / 64;
+        double2* b2 = reinterpret_cast<double2*>(buf);
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+            if (k * 64 + lane < PIECES) b2[k * 64 + lane] = make_double2(pre[2 * k], pre[2 * k + 1]);
+        fence();
+#pragma unroll
+        for (int j = 0; j < RD; ++j) v[j] = buf[lane * RD + j];
+        fence();
+    }
     template <int RD>
     static __device__ __forceinline__ void out(double* __restrict__ dst, size_t e0, int lane, double* buf, const double (&v)[RD]) {
         constexpr int PIECES = 64 * RD / 2;
@@ -159,10 +185,25 @@ struct L63Io {
 
 __device__ inline void l63_load(const EsdeArgs& a, size_t e, int p, L63In& x, const L63Io& io) {
     double Af[9], Sf[9];
-    L63Stage::load<9>(a.A, e, io.lane, io.wave_ok, io.buf, Af);
-    L63Stage::load<9>(a.S, e, io.lane, io.wave_ok, io.buf, Sf);
-    L63Stage::load<3>(a.b, e, io.lane, io.wave_ok, io.buf, x.b);
-    L63Stage::load<3>(a.m, e, io.lane, io.wave_ok, io.buf, x.m);
+    const size_t e0 = e - io.lane;
+    if (io.wave_ok && L63Stage::aligned(a.A + e0 * 9) && L63Stage::aligned(a.S + e0 * 9) &&
+        L63Stage::aligned(a.b + e0 * 3) && L63Stage::aligned(a.m + e0 * 3)) {
+        // all four arrays are requested before the first one is waited for
+        double pa[10], ps[10], pb[4], pm[4];
+        L63Stage::fetch<9>(a.A, e0, io.lane, pa);
+        L63Stage::fetch<9>(a.S, e0, io.lane, ps);
+        L63Stage::fetch<3>(a.b, e0, io.lane, pb);
+        L63Stage::fetch<3>(a.m, e0, io.lane, pm);
+        L63Stage::scatter<9>(pa, io.lane, io.buf, Af);
+        L63Stage::scatter<9>(ps, io.lane, io.buf, Sf);
+        L63Stage::scatter<3>(pb, io.lane, io.buf, x.b);
+        L63Stage::scatter<3>(pm, io.lane, io.buf, x.m);
+    } else {
+        L63Stage::load<9>(a.A, e, io.lane, false, io.buf, Af);
+        L63Stage::load<9>(a.S, e, io.lane, false, io.buf, Sf);
+        L63Stage::load<3>(a.b, e, io.lane, false, io.buf, x.b);
+        L63Stage::load<3>(a.m, e, io.lane, false, io.buf, x.m);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         x.iS[i] = a.sig_inv_diag[(size_t)p * a.sig_stride + i];
