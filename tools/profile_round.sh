@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiles behind the numbers in DESIGN.md and bench.py (run on the GPU box from the repository root):
+# Profiles behind the numbers the design notes and bench.py quote (run on the GPU box from the repository root):
 # kernel statistics of the bench command, HBM traffic counters (one pass per counter) and the
 # issue / busy counters of the Lorenz-96 energy kernel (two passes of at most eight SQ counters).
 set -e

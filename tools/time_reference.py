@@ -10,7 +10,7 @@ on the Lorenz-96 (D = 40, dt = 0.005, Euler) benchmark inputs, then the oracle
 (oracle/vgpa_oracle.py) on the same inputs.  Every worker process pins BLAS to one thread
 and evaluates its own independent problem; the rate is the sum over the workers, in
 (problem x time step) evaluations per second.  The reference does not exist on the GPU
-box, so the numbers this prints are recorded in BASELINE.md; bench.py times the oracle
+box, so the numbers this prints are kept as a tracked file under profiles/; bench.py times the oracle
 there and the ratio printed here converts that into a rate of the reference.
 
 Usage:  python tools/time_reference.py [--steps N] [--procs P] [--repeat R]
