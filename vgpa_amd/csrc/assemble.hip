@@ -80,6 +80,67 @@ obs_terms_nd_kernel(int N, int D, int M, const double* __restrict__ m, const dou
     if (l == 0) work[(size_t)p * M + n] = e_l;
 }
 
+// The same with the three D x D operators in LDS (rows padded by one double, so that lane l reading row l
+// is free of bank conflicts): four wavefronts per workgroup, OBS_PER_WG observations of one problem per
+// workgroup.  In the kernel above every lane walks a row of Ri and of Qi in global memory (forty cache lines
+// per load instruction at D = 40) and every observation is a workgroup of its own.  Same products and sums
+// in the same order: the same bits.
+constexpr int OBS_PER_WG = 8;
+__global__ void __launch_bounds__(256)
+obs_terms_nd_lds_kernel(int N, int D, int M, const double* __restrict__ m, const double* __restrict__ S,
+                        const int* __restrict__ obs_idx, const double* __restrict__ obsY, int obsY_stride,
+                        const double* __restrict__ H, const double* __restrict__ Ri, const double* __restrict__ Qi,
+                        double* __restrict__ work, double* __restrict__ dEobs_dm) {
+    extern __shared__ double lds[];
+    const int LD = D + 1, MS = D * LD;
+    double* Hs = lds;
+    double* Rs = Hs + MS;
+    double* Qs = Rs + MS;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    double* Wv = Qs + MS + w * 2 * D;          // W_n = y_n - m(t_n) H
+    double* Tv = Wv + D;                       // Ri W_n
+    for (int q = threadIdx.x; q < D * D; q += 256) {
+        const int r = q / D, c = q - r * D;
+        Hs[r * LD + c] = H[q];
+        Rs[r * LD + c] = Ri[q];
+        Qs[r * LD + c] = Qi[q];
+    }
+    __syncthreads();
+    const int p = blockIdx.y;
+    const size_t DD = (size_t)D * D;
+    const double* Y = obsY + (size_t)p * obsY_stride;
+    for (int n = blockIdx.x * OBS_PER_WG + w; n < M && n < (blockIdx.x + 1) * OBS_PER_WG; n += 4) {
+        const int tn = obs_idx[n];
+        const double* mt = m + ((size_t)p * N + tn) * D;
+        if (l < D) {
+            double hm = 0.0;
+            for (int i = 0; i < D; ++i) hm = fma(mt[i], Hs[i * LD + l], hm);
+            Wv[l] = Y[(size_t)n * D + l] - hm;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double e_l = 0.0;
+        if (l < D) {
+            double z = 0.0, t = 0.0;
+            for (int j = 0; j < D; ++j) {
+                z = fma(Wv[j], Qs[l * LD + j], z);
+                t = fma(Rs[l * LD + j], Wv[j], t);
+            }
+            Tv[l] = t;
+            e_l = z * z + Rs[l * LD + l] * S[((size_t)p * N + tn) * DD + (size_t)l * D + l];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (l < D) {
+            double gsum = 0.0;
+            for (int k = 0; k < D; ++k) gsum = fma(Hs[k * LD + l], Tv[k], gsum);
+            dEobs_dm[((size_t)p * N + tn) * D + l] = -gsum;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e_l += __shfl_xor(e_l, off, 64);
+        if (l == 0) work[(size_t)p * M + n] = e_l;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // Wv, Tv are rewritten by the next observation
+    }
+}
+
 // The same for D = 2, 3 with one LANE per (observation, problem): a wavefront per 3-vector leaves 61 lanes
 // idle and a grid of thousands of problems costs hundreds of thousands of one-wavefront workgroups.  Same
 // products and sums in the same order (the sum over components in the order of the shuffle tree above:
@@ -611,6 +672,10 @@ int obs_terms_impl(const char* who, int P, int N, int D, int M, int d, const dou
             else
                 hipLaunchKernelGGL(obs_terms_small_kernel<3>, dim3(grid), dim3(256), 0, st, P, N, M, m, S, obs_idx, obsY,
                                    obsY_stride, H, Ri, Qi, work, dEobs_dm);
+        } else if (M > 0 && sizeof(double) * (3 * D * (D + 1) + 8 * D) <= 64 * 1024) {
+            const size_t lds2 = sizeof(double) * (3 * D * (D + 1) + 8 * D);
+            hipLaunchKernelGGL(obs_terms_nd_lds_kernel, dim3((M + OBS_PER_WG - 1) / OBS_PER_WG, P), dim3(256), lds2, st, N, D,
+                               M, m, S, obs_idx, obsY, obsY_stride, H, Ri, Qi, work, dEobs_dm);
         } else if (M > 0) {
             hipLaunchKernelGGL(obs_terms_nd_kernel, dim3(M, P), dim3(64), lds, st, N, D, M, m, S, obs_idx, obsY,
                                obsY_stride, H, Ri, Qi, work, dEobs_dm);

@@ -122,6 +122,7 @@ class Problem:
     fun: Optional[object] = None   # user energy function evaluated on the host (system < 0)
     sde_struct: Optional[dict] = None
     kl0_cache: Optional[torch.Tensor] = field(default=None, repr=False)
+    jumps_cache: Optional[torch.Tensor] = field(default=None, repr=False)
 
     @property
     def M(self):
@@ -350,13 +351,17 @@ def obs_terms(prob, m, S):
     P, N, D = prob.P, prob.N, prob.D
     Eobs = torch.empty((P,), dtype=F64, device=m.device)
     dm = torch.empty_like(m)
-    jumpS = torch.empty((D, D) if D > 1 else (1,), dtype=F64, device=m.device)
+    # the jump of Psi at an observation, 0.5 H' Ri H, depends on the operators only: computed once per Problem
+    fresh = prob.jumps_cache is None
+    jumpS = torch.empty((D, D) if D > 1 else (1,), dtype=F64, device=m.device) if fresh else None
     d = prob.obsY.shape[-1]
     ystride = prob.M * d if (prob.obsY.dim() == 3 and P > 1) else 0
     work = torch.empty((P, max(prob.M, 1)), dtype=F64, device=m.device)
     call("vgpa_obs_terms", P, N, D, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
          _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(work), _p(Eobs), _p(dm), _p(jumpS), _stream())
-    return Eobs, dm, jumpS
+    if fresh:
+        prob.jumps_cache = jumpS
+    return Eobs, dm, prob.jumps_cache
 
 
 def kl0(prob):
