@@ -19,7 +19,8 @@ with the gradient assembly.  value = P_total * N * steps / time.
   neighbouring ranks, one all_reduce of the energy and hyper-gradient partial sums per
   step, M micro-batches of problems to pipeline the hand-offs.  Strong scaling.
 
-For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL).
+For N > 1 either launch it under torch.distributed.run (one rank per GPU, RCCL) or just run
+`python bench.py --gpus N`: outside a launcher it starts its own N ranks (launch_ranks).
 """
 import argparse
 import json
@@ -201,7 +202,46 @@ def parity_on_fixture(dev, copies=192):
             "F_rel_err": F_err, "grad_rel_err": g_err, "tol": 1e-9, "ok": bool(F_err <= 1e-9 and g_err <= 1e-9)}
 
 
-def main():
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside a launcher: time the CPU baseline here, then start the N
+    ranks as children of this process under torch.distributed.run (rendezvous on 127.0.0.1, a
+    free port), pass every argument through, print rank 0's JSON line with the CPU baseline
+    merged in and return the launcher's exit code.  This process never touches the GPU."""
+    import socket
+    import subprocess
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cpu = None if args.no_cpu else cpu_baseline(40, 0.005)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if "--no-cpu" not in argv:
+        cmd.append("--no-cpu")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        s_ = ln.strip()
+        if s_.startswith("{") and '"metric"' in s_:
+            try:
+                line = json.loads(s_)
+                continue
+            except ValueError:
+                pass
+        sys.stdout.write(ln)       # anything else the ranks print is passed on
+    rc = proc.wait()
+    if line is not None:
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        line["launcher"] = "bench.py started its own ranks (torch.distributed.run)"
+        print(json.dumps(line), flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -218,13 +258,15 @@ def main():
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the fixture check after the timed region (profiling runs: its small launches "
                          "of the same kernels would enter the per-kernel averages)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))      # not under a launcher: start the ranks ourselves
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        sys.exit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     D, N, dt, P = 40, 2002, 0.005, args.problems
     # the host driver of this pool shares device memory between processes through dmabuf only (RCCL's
     # hipIpcGetMemHandle fails otherwise); normally exported already, set before anything initialises HIP
@@ -408,7 +450,8 @@ def main():
             line["kernels"] = kernels
         else:
             line["config"] = {"workload": "Lorenz-96 UT, D=40, T=10, dt=0.005 (N=2002), Euler, "
-                                          f"{P} problems, each cut into {world} time windows, F + dL/dA, dL/db "
+                                          f"a batch of {P} problem(s) (--problems; 1 = the single long problem), "
+                                          f"every one cut into {world} time windows, F + dL/dA, dL/db "
                                           "+ dEsde/dtheta, dEsde/dSigma",
                               "problems": P, "micro_batches": len(ops), "N": N, "D": D,
                               "sharding": f"time windows x{world}",

@@ -239,6 +239,9 @@ int vgpa_obs_terms(int P, int N, int D, int M, int d,
  *     address of the array (hipGetSymbolAddress); make that first call outside a capture.
  *   - All calls on one GPU share the one array: calls that overlap on the same GPU (two
  *     streams, two threads) race.  Nothing a previous call left in it is read.
+ *   - Every GPU has its own copy of the array, found through the CURRENT device: the device
+ *     that owns `stream` (and the pointers) must be the current one.  A stream of another
+ *     device is refused with VGPA_EINVAL.
  */
 #define VGPA_OBS_STATIC_MAX (1 << 17)
 int vgpa_obs_terms_static(int P, int N, int D, int M, int d,

@@ -678,3 +678,93 @@ def test_lorenz63_energy_on_views_that_are_not_16_byte_aligned(system):
     for k in ("Esde_t", "Ef", "Edf", "dEdm", "dEdS", "dth_t", "dSig_t"):
         assert torch.equal(got[k], ref[k]), k
         assert torch.equal(got[k], full[k][1:]), k
+
+
+@pytest.mark.parametrize("method", ["EULER", "HEUN"])
+def test_small_dimension_scans_on_views_that_are_not_16_byte_aligned(method):
+    """The LDS-staged D = 3 scans move 16 bytes per lane; a contiguous batch that starts one odd-sized
+    problem into a larger allocation is only 8-byte aligned and must take the per-lane kernels, with the
+    same results as the same batch in allocations of its own."""
+    import torch
+    from vgpa_amd import engine
+    rng = np.random.default_rng(631)
+    P, N, D, dt = 5, 13, 3, 0.01      # N * D odd per problem is refused by the staged path anyway: use views
+    N = 14
+    A = engine.to_dev(4.0 * np.eye(D)[None, None] + 0.5 * rng.standard_normal((P, N + 1, D, D)))
+    b = engine.to_dev(rng.standard_normal((P, N + 1, D)))
+    gm, gS = engine.to_dev(rng.standard_normal((P, N + 1, D))), engine.to_dev(rng.standard_normal((P, N + 1, D, D)))
+    jm = engine.to_dev(rng.standard_normal((P, N + 1, D)))
+    m0 = engine.to_dev(rng.standard_normal((1, D)))
+    S0 = engine.to_dev(0.25 * np.eye(D)[None] + 0.05 * rng.standard_normal((1, D, D)))
+    Sig = engine.to_dev(2.0 * np.eye(D))
+    mid = engine.method_id(method)
+    # one problem, rows 1.. of its arrays: contiguous, base address 8 bytes off a 16-byte boundary
+    view = lambda t: t[0:1, 1:]       # noqa: E731
+    views = [view(t) for t in (A, b, gm, gS, jm)]
+    assert all(v.is_contiguous() for v in views)
+    assert views[0].data_ptr() % 16 == 8 and views[1].data_ptr() % 16 == 8
+    own = [v.clone() for v in views]
+    assert all(o.data_ptr() % 16 == 0 for o in own)
+    m1, S1 = engine.fwd_scan(mid, views[0], views[1], m0, S0, Sig, dt, symmetric=False)
+    m2, S2 = engine.fwd_scan(mid, own[0], own[1], m0, S0, Sig, dt, symmetric=False)
+    assert relerr(m1.cpu().numpy(), m2.cpu().numpy()) <= 1e-14 and relerr(S1.cpu().numpy(), S2.cpu().numpy()) <= 1e-14
+    l1, P1 = engine.bwd_scan(mid, views[0], views[2], views[3], views[4], dt)
+    l2, P2 = engine.bwd_scan(mid, own[0], own[2], own[3], own[4], dt)
+    assert relerr(l1.cpu().numpy(), l2.cpu().numpy()) <= 1e-14 and relerr(P1.cpu().numpy(), P2.cpu().numpy()) <= 1e-14
+    Ah, bh = own[0][0].cpu().numpy(), own[1][0].cpu().numpy()
+    mr, Sr = orc.fwd_scan(Ah, bh, m0[0].cpu().numpy(), S0[0].cpu().numpy(), Sig.cpu().numpy(), dt, method)
+    assert relerr(m1[0].cpu().numpy(), mr) <= TOL and relerr(S1[0].cpu().numpy(), Sr) <= TOL
+    lr, Pr = orc.bwd_scan(Ah, own[2][0].cpu().numpy(), own[3][0].cpu().numpy(), own[4][0].cpu().numpy(),
+                          np.zeros((N, D, D)), dt, method)
+    assert relerr(l1[0].cpu().numpy(), lr) <= TOL and relerr(P1[0].cpu().numpy(), Pr) <= TOL
+
+
+def test_gradient_notices_noise_edited_in_place_between_the_two_calls():
+    """gradL_Ab reads sde_struct['Sig'] when it is called (core/gradL_Ab.py:118-125): editing it in place after
+    varFreeEnergy must not leave the gradient with the inverse cached at publish time."""
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core.gradL_Ab import gradL_Ab
+    from vgpa_amd.core import _facade
+    g = load_golden("sys_l63_ut.npz")
+    sde = sde_from_golden(g, "EULER")
+    sde["Sig"] = np.array(sde["Sig"], dtype=np.float64, copy=True)
+    m0, S0 = initial_moments(g)
+    mParam = dict(m0=m0, S0=S0, fun=_dyn("l63_ut").energy_mode, sde_struct=sde)
+    Ab = np.array(g["Ab"], copy=True)
+    varFreeEnergy(Ab, mParam)
+    g0 = gradL_Ab(Ab, mParam)
+    sde["Sig"] *= 1.5
+    assert _facade.recall_published(mParam, *_dev_Ab(Ab, sde)) is None
+    g1 = gradL_Ab(Ab, mParam)
+    # what the upload path gives for the same arrays with the edited noise
+    keys = _facade.PUBLISHED_KEYS
+    want = gradL_Ab(Ab, {**mParam, **{k: np.array(mParam[k], copy=True) for k in keys}})
+    assert np.array_equal(g1, want) and not np.array_equal(g1, g0)
+
+
+def test_problem_caches_follow_replaced_operators():
+    """The jump of Psi (0.5 H' Ri H) and KL0 are cached on the Problem; replacing or editing H, Ri, m0, S0
+    must recompute them."""
+    import torch
+    from vgpa_amd import engine, _lib
+    g = load_golden("sys_l96_ut_d6.npz")
+    sde = sde_from_golden(g, "EULER")
+    m0, S0 = initial_moments(g)
+    N, D = sde["N"], sde["D"]
+    A, b = orc.unpack_Ab(g["Ab"], N, D)
+    prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=1)
+    Ad, bd = engine.to_dev(A[None]), engine.to_dev(b[None])
+    m, S = engine.fwd_scan(prob.method, Ad, bd, prob.m0, prob.S0, prob.Sigma, prob.dt)
+    _, _, j0 = engine.obs_terms(prob, m, S)
+    _, _, j0b = engine.obs_terms(prob, m, S)
+    assert j0b is j0                                  # cached
+    prob.H = (2.0 * prob.H).contiguous()              # reassigned
+    _, _, j1 = engine.obs_terms(prob, m, S)
+    assert torch.allclose(j1, 4.0 * j0, rtol=1e-14, atol=0)
+    prob.Ri.mul_(0.5)                                 # edited in place
+    _, _, j2 = engine.obs_terms(prob, m, S)
+    assert torch.allclose(j2, 2.0 * j0, rtol=1e-14, atol=0)
+    k0 = engine.kl0(prob).clone()
+    assert engine.kl0(prob) is engine.kl0(prob)
+    prob.m0 = prob.m0 + 0.3
+    assert not torch.equal(engine.kl0(prob), k0)

@@ -87,3 +87,43 @@ def test_static_scratch_entry_point_refuses_oversize():
     with pytest.raises(_lib.VgpaError, match="exceeds the fixed scratch"):
         _lib.call("vgpa_obs_terms_static", P, N, D, M, D, z.data_ptr(), z.data_ptr(), zi.data_ptr(), z.data_ptr(), 0,
                   z.data_ptr(), z.data_ptr(), z.data_ptr(), 0.0, z.data_ptr(), z.data_ptr(), z.data_ptr(), None)
+
+
+def test_static_scratch_entry_point_under_graph_capture():
+    """What the entry point is for: it can be recorded into a HIP graph (a capture fails on an allocation
+    or a synchronising call) and replayed on inputs changed in place, with the eager call's bits; device
+    memory in use does not change across a call."""
+    import torch
+    from vgpa_amd import _lib
+    P, N, D, M = 11, 40, 5, 9
+    m, S, obs_idx, obsY, H, Ri, Qi = _inputs(P, N, D, M, 5)
+    dev = m.device
+    Eobs = torch.empty((P,), dtype=torch.float64, device=dev)
+    dm = torch.empty((P, N, D), dtype=torch.float64, device=dev)
+    jumpS = torch.empty((D, D), dtype=torch.float64, device=dev)
+
+    def run():
+        _lib.call("vgpa_obs_terms_static", P, N, D, M, D, m.data_ptr(), S.data_ptr(), obs_idx.data_ptr(), obsY.data_ptr(),
+                  M * D, H.data_ptr(), Ri.data_ptr(), Qi.data_ptr(), 1.25, Eobs.data_ptr(), dm.data_ptr(), jumpS.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+
+    run()                                   # the first call on the device resolves the array's address
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    run()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for k in range(2):
+        m.add_(0.25 * (k + 1))
+        S.mul_(1.0 + 0.1 * (k + 1))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (Eobs.clone(), dm.clone(), jumpS.clone())
+        Eobs.fill_(float("nan")), dm.fill_(float("nan")), jumpS.fill_(float("nan"))
+        run()
+        torch.cuda.synchronize()
+        assert torch.isfinite(Eobs).all()
+        assert torch.equal(got[0], Eobs) and torch.equal(got[1], dm) and torch.equal(got[2], jumpS)

@@ -106,7 +106,16 @@ def remember_published(mParam, prob, Ad, bd, st):
         mParam[k].flags.writeable = False
     _published = dict(arrays={k: mParam[k] for k in PUBLISHED_KEYS},
                       prints={k: _fingerprint(mParam[k]) for k in PUBLISHED_KEYS},
-                      prob=prob, Ad=Ad, bd=bd, st=st, sde=mParam["sde_struct"], fun=mParam["fun"])
+                      prob=prob, Ad=Ad, bd=bd, st=st, sde=mParam["sde_struct"], fun=mParam["fun"],
+                      consumed=_consumed_by_gradient(mParam["sde_struct"]))
+
+
+def _consumed_by_gradient(sde):
+    """The entries of ``sde_struct`` the reference's gradL_Ab reads at call time
+    (core/gradL_Ab.py:56, :62, :118, :125), by value: a driver may edit the dictionary in
+    place between varFreeEnergy and gradL_Ab, and the cached problem must not outlive that."""
+    return (np.array(sde["Sig"], dtype=np.float64, copy=True).tobytes(), float(sde["dt"]),
+            str(sde.get("ode_method", "EULER")).upper())
 
 
 def recall_published(mParam, Ad, bd):
@@ -115,6 +124,8 @@ def recall_published(mParam, Ad, bd):
     import torch
     c = _published
     if c is None or mParam.get("sde_struct") is not c["sde"] or mParam.get("fun") is not c["fun"]:
+        return None
+    if _consumed_by_gradient(mParam["sde_struct"]) != c["consumed"]:
         return None
     for k in PUBLISHED_KEYS:
         a = mParam.get(k)

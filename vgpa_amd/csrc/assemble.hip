@@ -717,11 +717,22 @@ constexpr int kMaxDevices = 64;
 double* g_scratch_ptr[kMaxDevices] = {};
 std::mutex g_scratch_mutex;
 
-int scratch_for_current_device(double** out) {
+int scratch_for_current_device(hipStream_t st, double** out) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
         (void)hipGetLastError();
         return vgpa::fail(VGPA_ELAUNCH, "vgpa_obs_terms_static: cannot identify the current device");
+    }
+    // The array is looked up for the CURRENT device; a stream of another GPU would run the kernels
+    // there with this GPU's address.  (The null stream belongs to the current device.)
+    if (st) {
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice(st, &sdev) != hipSuccess) {
+            (void)hipGetLastError();
+        } else if ((int)sdev != dev) {
+            return vgpa::fail(VGPA_EINVAL, "vgpa_obs_terms_static: the stream belongs to device %d but device %d is "
+                              "current; make the stream's device current for this call", (int)sdev, dev);
+        }
     }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
@@ -755,7 +766,7 @@ extern "C" int vgpa_obs_terms_static(int P, int N, int D, int M, int d, const do
                           (size_t)P * (size_t)M, (int)VGPA_OBS_STATIC_MAX);
     if (P == 0) return VGPA_OK;
     double* work = nullptr;
-    const int rc = scratch_for_current_device(&work);
+    const int rc = scratch_for_current_device(vgpa::as_stream(stream), &work);
     if (rc != VGPA_OK) return rc;
     // every slot obs_finish_kernel reads (p * M + n, n < M) is written by obs_terms_nd_kernel of
     // this call first, so nothing left by an earlier call is ever read

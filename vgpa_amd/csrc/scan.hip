@@ -777,12 +777,21 @@ void allow_lds(K kernel, size_t bytes) {
 #define VGPA_SMALL_D_SCANS
 #include "small_d.h"
 
+// The LDS-staged D = 2, 3 scans move 16 bytes per lane on the caller's arrays: every array they touch
+// that way has to start on a 16-byte boundary (a contiguous view that begins at an odd row of a D = 3
+// array is only 8-byte aligned); the per-lane kernels take over otherwise.
+template <typename... Ptr>
+bool all_16_byte_aligned(Ptr... p) {
+    return (((reinterpret_cast<size_t>(p) & 15) == 0) && ...);
+}
+
 template <int METHOD>
 bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                       const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
     // RK4 evaluates the moment equations four times per step out of registers: its time is the
     // arithmetic chain of one lane, which the register-ring kernel below keeps shorter.
-    if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && METHOD != VGPA_RK4) {
+    if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && METHOD != VGPA_RK4 &&
+        all_16_byte_aligned(A, b, m_out, S_out)) {
         // 16-byte pieces through LDS, sixteen problems per wavefront
         const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
         if constexpr (METHOD == VGPA_EULER) {
@@ -809,7 +818,8 @@ template <int METHOD>
 bool launch_bwd_small(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                       const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                       const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
-    if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && !jS) {
+    if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && !jS &&
+        all_16_byte_aligned(A, dEdm, dEdS, jm, lam_out, Psi_out)) {
         const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
         if constexpr (METHOD == VGPA_EULER) {
             const size_t lds = sizeof(double) * SmallRows::bwd_lds_doubles(D);

@@ -121,8 +121,10 @@ class Problem:
     sym_jump: bool = False         # 0.5 H' Ri H is exactly symmetric (H, Ri diagonal)
     fun: Optional[object] = None   # user energy function evaluated on the host (system < 0)
     sde_struct: Optional[dict] = None
-    kl0_cache: Optional[torch.Tensor] = field(default=None, repr=False)
-    jumps_cache: Optional[torch.Tensor] = field(default=None, repr=False)
+    # (key, tensor): results that depend on a few fields only, recomputed when one of those
+    # fields is replaced or written in place (see _tensors_key)
+    kl0_cache: Optional[tuple] = field(default=None, repr=False)
+    jumps_cache: Optional[tuple] = field(default=None, repr=False)
 
     @property
     def M(self):
@@ -209,6 +211,31 @@ def make_problem(system, sde, m0, S0, P=1, theta=None, fun=None):
         isdiag = lambda M: np.count_nonzero(M - np.diag(np.diagonal(M))) == 0   # noqa: E731
         prob.sym_jump = bool(H.shape[0] == H.shape[1] and isdiag(H) and isdiag(Ri))
     return prob
+
+
+class _TensorsKey:
+    """The tensors a cached result was computed from, with their in-place version counters.
+    Unequal to a later key when a field has been reassigned to another tensor object or a
+    tensor has been written in place.  (It keeps the tensors alive, so a new tensor cannot
+    reuse the address of an old one unnoticed.)"""
+
+    def __init__(self, *tensors, extra=None):
+        self.tensors, self.versions, self.extra = tensors, tuple(t._version for t in tensors), extra
+
+    def __eq__(self, other):
+        return (isinstance(other, _TensorsKey) and len(self.tensors) == len(other.tensors)
+                and all(a is b for a, b in zip(self.tensors, other.tensors))
+                and self.versions == other.versions and self.extra == other.extra)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __deepcopy__(self, memo):
+        return None        # a copied Problem recomputes
+
+
+def _tensors_key(*tensors, extra=None):
+    return _TensorsKey(*tensors, extra=extra)
 
 
 def esde_output_is_symmetric(system, D):
@@ -351,8 +378,10 @@ def obs_terms(prob, m, S):
     P, N, D = prob.P, prob.N, prob.D
     Eobs = torch.empty((P,), dtype=F64, device=m.device)
     dm = torch.empty_like(m)
-    # the jump of Psi at an observation, 0.5 H' Ri H, depends on the operators only: computed once per Problem
-    fresh = prob.jumps_cache is None
+    # the jump of Psi at an observation, 0.5 H' Ri H, depends on the operators only: computed once
+    # per Problem and pair of operators
+    key = _tensors_key(prob.H, prob.Ri)
+    fresh = prob.jumps_cache is None or prob.jumps_cache[0] != key
     jumpS = torch.empty((D, D) if D > 1 else (1,), dtype=F64, device=m.device) if fresh else None
     d = prob.obsY.shape[-1]
     ystride = prob.M * d if (prob.obsY.dim() == 3 and P > 1) else 0
@@ -360,19 +389,20 @@ def obs_terms(prob, m, S):
     call("vgpa_obs_terms", P, N, D, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
          _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(work), _p(Eobs), _p(dm), _p(jumpS), _stream())
     if fresh:
-        prob.jumps_cache = jumpS
-    return Eobs, dm, prob.jumps_cache
+        prob.jumps_cache = (key, jumpS)
+    return Eobs, dm, prob.jumps_cache[1]
 
 
 def kl0(prob):
     """vgpa_kl0 -> KL0 (P,).  Independent of A, b: cached on the Problem."""
-    if prob.kl0_cache is None:
+    key = _tensors_key(prob.m0, prob.S0, prob.mu0, prob.tau0, extra=prob.m0_is_row)
+    if prob.kl0_cache is None or prob.kl0_cache[0] != key:
         P, D = prob.P, prob.D
         out = torch.empty((P,), dtype=F64, device=prob.m0.device)
         call("vgpa_kl0", P, D, _p(prob.m0), _p(prob.S0), _p(prob.mu0), _par_stride(prob.mu0, P, D),
              _p(prob.tau0), _par_stride(prob.tau0, P, D * D), int(prob.m0_is_row), _p(out), _stream())
-        prob.kl0_cache = out
-    return prob.kl0_cache
+        prob.kl0_cache = (key, out)
+    return prob.kl0_cache[1]
 
 
 def grad_assemble(prob, A, b, m, S, lam, Psi, Ef, Edf, outer=False, out=None):
