@@ -41,7 +41,7 @@ ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false>"
 KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel", "esde": ESDE_KERNEL,
                 "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
-STREAM_FILE = os.path.join(ROOT, "profiles", "r2_hbm_stream_probe.txt")
+STREAM_FILE = os.path.join(ROOT, "profiles", "r3_hbm_stream_probe.txt")
 # read / write streams of each kernel, as tools/diag/hbm_stream_probe names the mixes
 STREAM_MIX = {"fwd_scan": "1R1W", "esde": "2R1W", "bwd_scan_grad": "3R2W"}
 

@@ -768,3 +768,73 @@ def test_problem_caches_follow_replaced_operators():
     assert engine.kl0(prob) is engine.kl0(prob)
     prob.m0 = prob.m0 + 0.3
     assert not torch.equal(engine.kl0(prob), k0)
+
+
+def test_full_size_double_well_against_oracle():
+    """Double-well at its benchmark size (T = 50, dt = 0.01: N = 5001 rows from np.arange, two observations per
+    time unit) through the reference-signature entry points: F, the gradient column and every array
+    varFreeEnergy publishes against the oracle, all four integrators."""
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core.gradL_Ab import gradL_Ab
+    from vgpa_amd.dynamics import sys_double_well
+    rng = np.random.default_rng(5001)
+    Tw = np.arange(0.0, 50.0 + 0.01, 0.01)
+    N, dt = Tw.shape[0], 0.01
+    assert N == 5001
+    M = int(np.floor(50.0 * 2))
+    obsX = np.linspace(0, N, M + 2, dtype=int)[1:-1]
+    A = 0.5 * 0.8 / 0.25 + 0.3 * rng.standard_normal(N)
+    b = rng.standard_normal(N)
+    Ab = np.concatenate((A, b))[:, None]
+    for method in METHODS:
+        sde = dict(Sig=0.8, theta=1.0, Rig=0.04, D=1, N=N, H=1.0, obsX=obsX, obsY=rng.standard_normal((M, 1)),
+                   px0=dict(mu0=1.0, tau0=0.5), dt=dt, ode_method=method, Tw=Tw, checkGradf=False)
+        m0, S0 = np.array([1.1]), 0.25
+        mParam = dict(m0=m0, S0=S0, fun=sys_double_well.energy_mode, sde_struct=sde)
+        F = varFreeEnergy(Ab, mParam)
+        grad = gradL_Ab(Ab, mParam)
+        ref = orc.evaluate("dw", Ab, m0, S0, sde)
+        assert abs(F - ref["F"]) <= TOL * abs(ref["F"]), method
+        assert grad.shape == (2 * N, 1) and relerr(grad, ref["grad"]) <= TOL, method
+        for key, rk in (("mt", "m"), ("St", "S"), ("lamt", "lam"), ("Psit", "Psi"), ("Efx", "Ef"), ("Edf", "Edf")):
+            assert mParam[key].shape == (N, 1), key
+            assert relerr(mParam[key], np.asarray(ref[rk]).reshape(N, 1)) <= TOL, (method, key)
+
+
+@pytest.mark.parametrize("system", ["l63", "l63_ut"])
+def test_full_size_lorenz63_grid_against_oracle(system):
+    """The grid search at its benchmark size: 4096 = 16 x 16 x 16 drift parameters (sigma, rho, beta), T = 20,
+    dt = 0.01 (N = 2002 rows), five observations per time unit shared by all problems, one batched evaluation;
+    problems from both ends and the middle of the grid against the oracle's evaluation of that problem alone
+    (F, gradient, hyper-gradients and the moments)."""
+    import torch
+    from vgpa_amd import engine, _lib
+    D, N, dt, P = 3, 2002, 0.01, 4096
+    rng = np.random.default_rng(4096)
+    M = int(np.floor((N - 1) * dt * 5))
+    obsX = np.linspace(0, N, M + 2, dtype=int)[1:-1]
+    mu0 = np.array([1.0, -1.0, 20.0])
+    sde = dict(Sig=10.0 * np.eye(D), theta=np.array([10.0, 28.0, 8.0 / 3.0]), Rig=2.0 * np.eye(D), D=D, N=N,
+               H=np.eye(D), obsX=obsX, obsY=mu0[None] + 2.0 * rng.standard_normal((M, D)),
+               px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)), dt=dt, ode_method="EULER")
+    s_, r_, b_ = np.meshgrid(np.linspace(6, 16, 16), np.linspace(24, 34, 16), np.linspace(1, 4, 16), indexing="ij")
+    thetas = np.stack((s_.ravel(), r_.ravel(), b_.ravel()), axis=1)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(63)
+    A = 0.3 * torch.randn((P, N, D, D), generator=gen, device=dev, dtype=torch.float64)
+    A += 20.0 * torch.eye(D, device=dev, dtype=torch.float64)
+    b = 20.0 * torch.randn((P, N, D), generator=gen, device=dev, dtype=torch.float64)
+    m0, S0 = mu0 + 0.1, 0.25 * np.eye(D)
+    prob = engine.make_problem(_lib.SYSTEMS[system], sde, m0, S0, P=P, theta=thetas)
+    st, gLA, gLb = engine.free_energy_and_gradient(prob, A, b, want_hyper=True)
+    assert int(st.status.max().item()) == 0 and bool(torch.isfinite(st.F).all())
+    for p in (0, 1, 2047, 2048, 4095):
+        Ab = np.concatenate((A[p].reshape(-1).cpu().numpy(), b[p].reshape(-1).cpu().numpy()))
+        ref = orc.evaluate(system, Ab, m0, S0, dict(sde, theta=thetas[p]))
+        assert abs(st.F[p].item() - ref["F"]) <= TOL * abs(ref["F"]), p
+        got = np.concatenate((gLA[p].reshape(-1).cpu().numpy(), gLb[p].reshape(-1).cpu().numpy()))
+        assert relerr(got, ref["grad"]) <= TOL, p
+        assert relerr(st.dth[p].cpu().numpy(), ref["dEsde_dth"]) <= TOL, p
+        assert relerr(st.dSig[p].cpu().numpy(), ref["dEsde_dSig"]) <= TOL, p
+        for name, rk in (("m", "m"), ("S", "S"), ("lam", "lam"), ("Psi", "Psi"), ("dEdS", "dEsde_dS")):
+            assert relerr(getattr(st, name)[p].cpu().numpy(), ref[rk]) <= TOL, (p, name)

@@ -652,12 +652,23 @@ extern "C" int vgpa_reduce_energy(int P, int N, int C, const double* x, const do
 
 namespace {
 
+// Zero-fill of dEobs/dm by a kernel of this library rather than hipMemsetAsync: recorded into a HIP graph,
+// the runtime's memset node filled the array with other values from the second replay on (seen with ROCm 7.2
+// on gfx950: every element non-zero after a replay, correct in eager mode and at the first replay).
+__global__ void zero_fill_kernel(double* __restrict__ x, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = 0.0;
+}
+
 int obs_terms_impl(const char* who, int P, int N, int D, int M, int d, const double* m, const double* S,
                    const int* obs_idx, const double* obsY, int obsY_stride, const double* H, const double* Ri,
                    const double* Qi, double logconst, double* work, double* Eobs, double* dEobs_dm, double* jumpS,
                    hipStream_t st) {
-    hipError_t me = hipMemsetAsync(dEobs_dm, 0, sizeof(double) * (size_t)P * N * D, st);
-    if (me != hipSuccess) return vgpa::fail(VGPA_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(me));
+    {
+        const size_t n = (size_t)P * N * D;
+        const size_t want = (n + 255) / 256;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, dEobs_dm, n);
+    }
     if (D == 1) {
         const int bs = 64, grid = (P + bs - 1) / bs;
         hipLaunchKernelGGL(obs_terms_1d_kernel, dim3(grid), dim3(bs), 0, st, P, N, M, m, S, obs_idx, obsY,

@@ -54,7 +54,7 @@ struct M40Rows {
         const double2* s2 = reinterpret_cast<const double2*>(src) + lr * (D / 2) + lc;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const double2 v = (i < NQ - 1) ? s2[i * 3 * (D / 2)] : s2[i * 3 * (D / 2) - lr * (D / 2)];
+            const double2 v = vgpa::ld_once((i < NQ - 1) ? s2 + i * 3 * (D / 2) : s2 + i * 3 * (D / 2) - lr * (D / 2));
             pre[2 * i] = v.x;
             pre[2 * i + 1] = v.y;
         }
@@ -89,7 +89,7 @@ struct M40Rows {
         for (int i = 0; i < NQ; ++i) {
             const double* sp = (i < NQ - 1) ? s0 + 3 * i * LD : s0 + 3 * i * LD - lr * LD;
             double2* dp = (i < NQ - 1) ? d2 + i * 3 * (D / 2) : d2 + i * 3 * (D / 2) - lr * (D / 2);
-            *dp = *reinterpret_cast<const double2*>(sp);
+            vgpa::st_once(dp, *reinterpret_cast<const double2*>(sp));
         }
     }
 };
@@ -103,7 +103,7 @@ struct M40Third {
         const double2* s2 = reinterpret_cast<const double2*>(src);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double2 v = s2[min(piece(r, lane, q), M40::DD / 2 - 1)];
+            const double2 v = vgpa::ld_once(s2 + min(piece(r, lane, q), M40::DD / 2 - 1));
             pre[2 * q] = v.x;
             pre[2 * q + 1] = v.y;
         }
@@ -340,7 +340,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) out[L.g[c][reg]] = dt * (z[c][reg] - s12);   // core/gradL_Ab.py:170, :176
+                for (int reg = 0; reg < 4; ++reg) vgpa::st_once(out + L.g[c][reg], dt * (z[c][reg] - s12));   // core/gradL_Ab.py:170, :176
             M40F_STAMP(3);
         }
     } else {

@@ -140,7 +140,7 @@ struct M40Wave {
         const double2* s2 = reinterpret_cast<const double2*>(src);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double2 v = s2[min(piece(lane, q), M40::DD / 2 - 1)];
+            const double2 v = vgpa::ld_once(s2 + min(piece(lane, q), M40::DD / 2 - 1));
             pre[2 * q] = v.x;
             pre[2 * q + 1] = v.y;
         }
@@ -166,7 +166,7 @@ struct M40Wave {
         double2* d2 = reinterpret_cast<double2*>(dst);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (valid(lane, q)) d2[piece(lane, q)] = *reinterpret_cast<const double2*>(src + lds_off(lane, q));
+            if (valid(lane, q)) vgpa::st_once(d2 + piece(lane, q), *reinterpret_cast<const double2*>(src + lds_off(lane, q)));
         }
     }
 };
