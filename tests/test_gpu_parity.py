@@ -801,15 +801,17 @@ def test_full_size_double_well_against_oracle():
             assert relerr(mParam[key], np.asarray(ref[rk]).reshape(N, 1)) <= TOL, (method, key)
 
 
+@pytest.mark.parametrize("P", [4096, 512])
 @pytest.mark.parametrize("system", ["l63", "l63_ut"])
-def test_full_size_lorenz63_grid_against_oracle(system):
+def test_full_size_lorenz63_grid_against_oracle(system, P):
     """The grid search at its benchmark size: 4096 = 16 x 16 x 16 drift parameters (sigma, rho, beta), T = 20,
     dt = 0.01 (N = 2002 rows), five observations per time unit shared by all problems, one batched evaluation;
     problems from both ends and the middle of the grid against the oracle's evaluation of that problem alone
-    (F, gradient, hyper-gradients and the moments)."""
+    (F, gradient, hyper-gradients and the moments).  P = 512 is one GPU's share of the grid on eight GPUs (every
+    eighth grid point here), which takes the scans that are parallel in time."""
     import torch
     from vgpa_amd import engine, _lib
-    D, N, dt, P = 3, 2002, 0.01, 4096
+    D, N, dt = 3, 2002, 0.01
     rng = np.random.default_rng(4096)
     M = int(np.floor((N - 1) * dt * 5))
     obsX = np.linspace(0, N, M + 2, dtype=int)[1:-1]
@@ -818,7 +820,7 @@ def test_full_size_lorenz63_grid_against_oracle(system):
                H=np.eye(D), obsX=obsX, obsY=mu0[None] + 2.0 * rng.standard_normal((M, D)),
                px0=dict(mu0=mu0, tau0=0.5 * np.eye(D)), dt=dt, ode_method="EULER")
     s_, r_, b_ = np.meshgrid(np.linspace(6, 16, 16), np.linspace(24, 34, 16), np.linspace(1, 4, 16), indexing="ij")
-    thetas = np.stack((s_.ravel(), r_.ravel(), b_.ravel()), axis=1)
+    thetas = np.stack((s_.ravel(), r_.ravel(), b_.ravel()), axis=1)[::4096 // P]
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(63)
     A = 0.3 * torch.randn((P, N, D, D), generator=gen, device=dev, dtype=torch.float64)
@@ -828,7 +830,7 @@ def test_full_size_lorenz63_grid_against_oracle(system):
     prob = engine.make_problem(_lib.SYSTEMS[system], sde, m0, S0, P=P, theta=thetas)
     st, gLA, gLb = engine.free_energy_and_gradient(prob, A, b, want_hyper=True)
     assert int(st.status.max().item()) == 0 and bool(torch.isfinite(st.F).all())
-    for p in (0, 1, 2047, 2048, 4095):
+    for p in (0, 1, P // 2 - 1, P // 2, P - 1):
         Ab = np.concatenate((A[p].reshape(-1).cpu().numpy(), b[p].reshape(-1).cpu().numpy()))
         ref = orc.evaluate(system, Ab, m0, S0, dict(sde, theta=thetas[p]))
         assert abs(st.F[p].item() - ref["F"]) <= TOL * abs(ref["F"]), p
@@ -838,3 +840,44 @@ def test_full_size_lorenz63_grid_against_oracle(system):
         assert relerr(st.dSig[p].cpu().numpy(), ref["dEsde_dSig"]) <= TOL, p
         for name, rk in (("m", "m"), ("S", "S"), ("lam", "lam"), ("Psi", "Psi"), ("dEdS", "dEsde_dS")):
             assert relerr(getattr(st, name)[p].cpu().numpy(), ref[rk]) <= TOL, (p, name)
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("D,N", [(3, 65), (3, 66), (3, 130), (3, 2002), (3, 20000), (2, 65), (2, 2002), (2, 5001)])
+def test_small_dimension_scans_parallel_in_time_vs_sequential_oracle(D, N, method):
+    """D = 2, 3 with few problems: the time axis is cut into sixteen chunks that are integrated side by
+    side (basis states through each chunk, start states chunk after chunk, rows again from the start
+    states).  One step past the shortest length the path takes, chunk lengths that do not divide the steps,
+    the benchmark length and a long one; non-symmetric states, flagged jumps and a terminal state; every
+    problem against the oracle, which walks the rows one by one as the reference does."""
+    import torch
+    from vgpa_amd import engine
+    rng = np.random.default_rng(100 * D + N + len(method))
+    P, dt = 3, 0.01
+    A = 4.0 * np.eye(D)[None, None] + 0.5 * rng.standard_normal((P, N, D, D))
+    b = rng.standard_normal((P, N, D))
+    m0 = rng.standard_normal((P, D))
+    S0 = 0.25 * np.eye(D)[None] + 0.05 * rng.standard_normal((P, D, D))
+    Sig = 2.0 * np.eye(D) + 0.1 * rng.standard_normal((D, D))
+    gm, gS = rng.standard_normal((P, N, D)), rng.standard_normal((P, N, D, D))
+    jm = rng.standard_normal((P, N, D))
+    flag = (rng.random(N) < 0.05).astype(np.int32)
+    jump = rng.standard_normal((D, D))
+    lamT, PsiT = rng.standard_normal((P, D)), rng.standard_normal((P, D, D))
+    d = engine.to_dev
+    mid = engine.method_id(method)
+    m1, S1 = engine.fwd_scan(mid, d(A), d(b), d(m0), d(S0), d(Sig), dt, symmetric=False)
+    l1, P1 = engine.bwd_scan(mid, d(A), d(gm), d(gS), d(jm), dt, obs_flag=torch.from_numpy(flag).to(m1.device),
+                             jumpS=d(jump), lam_last=d(lamT), Psi_last=d(PsiT))
+    jS = flag[:, None, None] * jump[None]
+    for p in range(P):
+        mr, Sr = orc.fwd_scan(A[p], b[p], m0[p], S0[p], Sig, dt, method)
+        lr, Pr = orc.bwd_scan(A[p], gm[p], gS[p], jm[p], jS, dt, method, lam_last=lamT[p], Psi_last=PsiT[p])
+        for got, want in ((m1[p], mr), (S1[p], Sr), (l1[p], lr), (P1[p], Pr)):
+            assert relerr(got.cpu().numpy(), want) <= 1e-11, p
+    # without flags and terminal state (null pointers), one problem alone: the bits it has inside a batch
+    m2, S2 = engine.fwd_scan(mid, d(A[-1:]), d(b[-1:]), d(m0[-1:]), d(S0[-1:]), d(Sig), dt, symmetric=False)
+    assert torch.equal(S2[0], S1[-1]) and torch.equal(m2[0], m1[-1])
+    l3, P3 = engine.bwd_scan(mid, d(A[:1]), d(gm[:1]), d(gS[:1]), d(jm[:1]), dt)
+    lr, Pr = orc.bwd_scan(A[0], gm[0], gS[0], jm[0], np.zeros((N, D, D)), dt, method)
+    assert relerr(l3[0].cpu().numpy(), lr) <= 1e-11 and relerr(P3[0].cpu().numpy(), Pr) <= 1e-11

@@ -776,6 +776,7 @@ void allow_lds(K kernel, size_t bytes) {
 #include "scan_fused_stages2.h"
 #define VGPA_SMALL_D_SCANS
 #include "small_d.h"
+#include "small_d_chunks.h"
 
 // The LDS-staged D = 2, 3 scans move 16 bytes per lane on the caller's arrays: every array they touch
 // that way has to start on a 16-byte boundary (a contiguous view that begins at an odd row of a D = 3
@@ -788,6 +789,12 @@ bool all_16_byte_aligned(Ptr... p) {
 template <int METHOD>
 bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                       const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
+    if ((D == 2 || D == 3) && SmallChunks::use(P, N)) {
+        // few problems: sixteen chunks of the time axis per problem side by side
+        if (D == 2) hipLaunchKernelGGL((fwd_scan_small_chunks_kernel<2, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
+        else hipLaunchKernelGGL((fwd_scan_small_chunks_kernel<3, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
+        return true;
+    }
     // RK4 evaluates the moment equations four times per step out of registers: its time is the
     // arithmetic chain of one lane, which the register-ring kernel below keeps shorter.
     if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && METHOD != VGPA_RK4 &&
@@ -818,6 +825,11 @@ template <int METHOD>
 bool launch_bwd_small(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                       const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                       const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
+    if ((D == 2 || D == 3) && !jS && SmallChunks::use(P, N)) {
+        if (D == 2) hipLaunchKernelGGL((bwd_scan_small_chunks_kernel<2, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+        else hipLaunchKernelGGL((bwd_scan_small_chunks_kernel<3, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+        return true;
+    }
     if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && !jS &&
         all_16_byte_aligned(A, dEdm, dEdS, jm, lam_out, Psi_out)) {
         const unsigned gl = (unsigned)((P + SmallLds::PB - 1) / SmallLds::PB);
