@@ -43,12 +43,12 @@ def counters(sub):
 
 # 2. HBM traffic
 fe, wr = counters("fetch"), counters("write")
-units = 256 * 2002
+units = 512 * 2002
 alg = {"fwd_euler_sym_mfma40_kernel": 26240, "esde_l96_ut_wave40_kernel<false>": 39688, "bwd_grad_euler_sym_mfma40_kernel": 66240}
 text = [f"# HBM traffic per launch from rocprofv3 PMC counters ({tag})",
-        "# commands (two separate passes): rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity --problems 256",
-        "#                                 rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity --problems 256",
-        f"# workload: Lorenz-96 D=40 N=2002, 256 problems = {units} problem*timesteps per launch (averages over the launches of each kernel)",
+        "# commands (two separate passes): rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity   (512 problems, the size bench.py times)",
+        "#                                 rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity   (512 problems, the size bench.py times)",
+        f"# workload: Lorenz-96 D=40 N=2002, 512 problems = {units} problem*timesteps per launch (averages over the launches of each kernel)",
         "# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane",
         "# coalesced streaming reads (128-byte requests tallied as 64), so reads are doubled.",
         "# bench.py reads the LAST line below whose first field is the kernel it reports the roofline for.",
@@ -64,8 +64,8 @@ for name in (f"{tag}_pmc_hbm_traffic.txt", "pmc_hbm_traffic.txt"):
 k = "esde_l96_ut_wave40_kernel<false>"
 sq = dict(counters("sq_a")[k]); sq.update(counters("sq_b")[k])
 steps = units
-lines = [f"# rocprofv3 --pmc <counters> -- python3 tools/diag/esde_only.py 256   ({tag}; two passes; averages over 3 launches of {k},",
-         f"# 256 problems x 2002 steps = {steps} wavefronts, one per step)",
+lines = [f"# rocprofv3 --pmc <counters> -- python3 tools/diag/esde_only.py 512   ({tag}; two passes; averages over 3 launches of {k},",
+         f"# 512 problems x 2002 steps = {steps} wavefronts, one per step)",
          "# SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts; SQ_VALU_MFMA_BUSY_CYCLES counts cycles",
          "counter,value,per_step"]
 for c in sorted(sq):

@@ -35,5 +35,3 @@ def run(system, x0, theta, kdiag, ek, dt, burn=0, dtau=0.0, add0=None):
                          None if add0 is None else d(np.asarray(add0, dtype=np.float64).reshape(1, D)))
     return X[0].cpu().numpy()
 
-
-SYS = _lib
