@@ -364,7 +364,8 @@ def main(argv=None):
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            # RCCL picks the device of a barrier from the rank unless told: name it
+            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
