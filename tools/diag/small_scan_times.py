@@ -38,7 +38,8 @@ for P in Ps:
         (m, S), tf = timed(lambda: engine.fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd))
         Eobs, dEobs_dm, jumpS = engine.obs_terms(prob, m, S)
         en, te = timed(lambda: engine.esde(prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
+        sym = prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D)
         (lam, Psi), tb = timed(lambda: engine.bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
-                                                       obs_flag=prob.obs_flag, jumpS=jumpS))
+                                                       obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym))
         _, tall = timed(lambda: engine.free_energy_and_gradient(prob, A, b))
-        print(f"P={P:5d} {name:7s} {sde['ode_method']:5s} fwd {tf:7.3f} ms  esde {te:7.3f}  bwd {tb:7.3f}  F+grad {tall:7.3f} ms", flush=True)
+        print(f"P={P:5d} {name:7s} {sde['ode_method']:5s} fwd {tf:7.3f} ms  esde {te:7.3f}  bwd {tb:7.3f} (sym {int(sym)})  F+grad {tall:7.3f} ms", flush=True)

@@ -786,13 +786,13 @@ bool all_16_byte_aligned(Ptr... p) {
     return (((reinterpret_cast<size_t>(p) & 15) == 0) && ...);
 }
 
-template <int METHOD>
+template <int METHOD, bool SYM>
 bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                       const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
     if ((D == 2 || D == 3) && SmallChunks::use(P, N)) {
-        // few problems: sixteen chunks of the time axis per problem side by side
-        if (D == 2) hipLaunchKernelGGL((fwd_scan_small_chunks_kernel<2, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
-        else hipLaunchKernelGGL((fwd_scan_small_chunks_kernel<3, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
+        // few problems: 16 (32 with symmetric state) chunks of the time axis per problem side by side
+        if (D == 2) hipLaunchKernelGGL((fwd_scan_small_chunks_kernel<2, METHOD, SYM>), dim3(P), dim3(256), 0, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
+        else hipLaunchKernelGGL((fwd_scan_small_chunks_kernel<3, METHOD, SYM>), dim3(P), dim3(256), 0, st, N, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out);
         return true;
     }
     // RK4 evaluates the moment equations four times per step out of registers: its time is the
@@ -821,13 +821,13 @@ bool launch_fwd_small(int P, int N, int D, const double* A, const double* b, con
     return true;
 }
 
-template <int METHOD>
+template <int METHOD, bool SYM>
 bool launch_bwd_small(int P, int N, int D, const double* A, const double* dEdm, const double* dEdS, const double* jm,
                       const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                       const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
     if ((D == 2 || D == 3) && !jS && SmallChunks::use(P, N)) {
-        if (D == 2) hipLaunchKernelGGL((bwd_scan_small_chunks_kernel<2, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
-        else hipLaunchKernelGGL((bwd_scan_small_chunks_kernel<3, METHOD>), dim3(P), dim3(SmallChunks::NT), 0, st, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+        if (D == 2) hipLaunchKernelGGL((bwd_scan_small_chunks_kernel<2, METHOD, SYM>), dim3(P), dim3(256), 0, st, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
+        else hipLaunchKernelGGL((bwd_scan_small_chunks_kernel<3, METHOD, SYM>), dim3(P), dim3(256), 0, st, N, A, dEdm, dEdS, jm, obs_flag, jumpS, jumpS_stride, dt, lam_last, Psi_last, lam_out, Psi_out);
         return true;
     }
     if ((D == 2 || D == 3) && ((long long)N * D) % 2 == 0 && !jS &&
@@ -856,7 +856,7 @@ template <int METHOD, int DT, bool SYM>
 void launch_fwd(int P, int N, int D, const double* A, const double* b, const double* m0, const double* S0,
                 const double* Sigma, int sigma_stride, double dt, double* m_out, double* S_out, hipStream_t st) {
     if constexpr (DT == 0) {
-        if (launch_fwd_small<METHOD>(P, N, D, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out, st)) return;
+        if (launch_fwd_small<METHOD, SYM>(P, N, D, A, b, m0, S0, Sigma, sigma_stride, dt, m_out, S_out, st)) return;
     }
     if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
         const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
@@ -883,7 +883,7 @@ void launch_bwd(int P, int N, int D, const double* A, const double* dEdm, const 
                 const double* jS, const int* obs_flag, const double* jumpS, int jumpS_stride, double dt,
                 const double* lam_last, const double* Psi_last, double* lam_out, double* Psi_out, hipStream_t st) {
     if constexpr (DT == 0) {
-        if (launch_bwd_small<METHOD>(P, N, D, A, dEdm, dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_last,
+        if (launch_bwd_small<METHOD, SYM>(P, N, D, A, dEdm, dEdS, jm, jS, obs_flag, jumpS, jumpS_stride, dt, lam_last,
                                      Psi_last, lam_out, Psi_out, st)) return;
     }
     if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {

@@ -20,6 +20,12 @@
 // dependent steps replace one pass of N - 1.  Same step arithmetic as the other small-D kernels
 // (SmallD::fwd_step / bwd_step).
 //
+// SYM (the caller's promise that the state is exactly symmetric: S0, Sigma forward; dEsde/dS, the jumps and
+// the terminal state backward): a basis of symmetric matrices has D (D + 1) / 2 members, so a chunk needs
+// eight lanes instead of sixteen and a workgroup cuts the time axis into 32 chunks.  The step function is the
+// general one -- it maps an exactly symmetric state to an exactly symmetric state -- so the rows are those of the
+// sixteen-chunk kernel up to the chunk start states.
+//
 // Input rows reach the lanes through LDS: the sixteen lanes of a chunk copy the rows of the next T steps
 // (two buffers per chunk) while the current ones are integrated, so the latency of a global load
 // (about 2000 cycles here, as long as a step) is paid once per T steps and hidden behind them.  Read
@@ -27,30 +33,55 @@
 //
 // Included by scan.hip after small_d.h, inside its anonymous namespace.
 
+template <bool SYM>
+struct SmallChunksT {
+    static constexpr int NT = 256, WAVES = NT / 64;
+    static constexpr int ROW = SYM ? 8 : 16;          // lanes per chunk
+    static constexpr int C = NT / ROW, CPW = 64 / ROW;   // chunks per workgroup / per wavefront
+    static constexpr int T_FWD = SYM ? 4 : 8, T_BWD = SYM ? 2 : 4;       // steps per staged tile (LDS: two workgroups per CU)
+    // members of the basis the state is expanded in (the forcing role comes after them)
+    static constexpr int nbasis(int D) { return SYM ? D * (D + 1) / 2 : D * D; }
+    // member q: the matrix with ones at (i, j) and (j, i); general basis: q = i D + j
+    template <int D>
+    static __device__ __forceinline__ void member(int q, int& i, int& j) {
+        if (SYM) {
+            i = 0;
+            int left = q;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const bool next = left >= D - k && i == k;
+                left -= next ? D - k : 0;
+                i += next ? 1 : 0;
+            }
+            j = i + left;
+        } else {
+            i = q / D;
+            j = q % D;
+        }
+    }
+};
 struct SmallChunks {
-    static constexpr int C = 16, ROW = 16, NT = C * ROW, WAVES = NT / 64, CPW = 64 / ROW;   // CPW chunks per wavefront
-    static constexpr int T_FWD = 8, T_BWD = 4;       // steps per staged tile
     // worth it when the sequential kernels leave most of the chip idle and a chunk has some length
-    static bool use(int P, int N) { return P <= 1024 && N - 1 >= 4 * C; }
+    static bool use(int P, int N) { return P <= 1024 && N - 1 >= 4 * 32; }
 };
 
-// One chunk's staging area: ROWS rows of RW doubles, copied by the chunk's sixteen lanes.
-template <int RW, int ROWS>
+// One chunk's staging area: ROWS rows of RW doubles, copied by the chunk's LPC lanes.
+template <int RW, int ROWS, int LPC>
 struct ChunkTile {
-    static constexpr int TILE = RW * ROWS, NL = (TILE + 15) / 16;
-    // element e = r + 16 j of the tile: (row e / RW, entry e % RW); `src(row_index, entry)` names its address
+    static constexpr int TILE = RW * ROWS, NL = (TILE + LPC - 1) / LPC;
+    // element e = r + LPC j of the tile: (row e / RW, entry e % RW); `src(row_index, entry)` names its address
     template <typename Src>
     static __device__ __forceinline__ void fetch(int r, Src src, double (&pre)[NL]) {
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int e = min(r + 16 * j, TILE - 1);
+            const int e = min(r + LPC * j, TILE - 1);
             pre[j] = *src(e / RW, e % RW);
         }
     }
     static __device__ __forceinline__ void commit(int r, const double (&pre)[NL], double* tile) {
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int e = r + 16 * j;
+            const int e = r + LPC * j;
             if (j < NL - 1 || e < TILE) tile[e] = pre[j];
         }
     }
@@ -58,20 +89,20 @@ struct ChunkTile {
 
 __device__ __forceinline__ void chunk_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-template <int D, int METHOD>
-__global__ void __launch_bounds__(SmallChunks::NT, 2)
+template <int D, int METHOD, bool SYM>
+__global__ void __launch_bounds__(256, 2)
 fwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* __restrict__ b,
                              const double* __restrict__ m0, const double* __restrict__ S0,
                              const double* __restrict__ Sigma, int sigma_stride, double dt,
                              double* __restrict__ m_out, double* __restrict__ S_out) {
     using T = SmallD<D>;
-    using K = SmallChunks;
-    constexpr int DD = T::DD, NS = D + DD, TS = K::T_FWD, RW = DD + D;
-    using Tile = ChunkTile<RW, TS + 1>;                    // rows t .. t + TS of [A | b]
-    __shared__ double ops[K::C][DD + 1][NS];     // what the roles' states became over the chunk
+    using K = SmallChunksT<SYM>;
+    constexpr int DD = T::DD, NS = D + DD, TS = K::T_FWD, RW = DD + D, NB = K::nbasis(D);
+    using Tile = ChunkTile<RW, TS + 1, K::ROW>;                    // rows t .. t + TS of [A | b]
+    __shared__ double ops[K::C][NB + 1][NS];     // what the roles' states became over the chunk
     __shared__ double starts[K::C][NS];          // the state at the first row of every chunk
     __shared__ double tiles[K::WAVES][2][K::CPW][Tile::TILE];
-    const int tid = threadIdx.x, c = tid >> 4, r = tid & 15;
+    const int tid = threadIdx.x, c = tid / K::ROW, r = tid % K::ROW;
     const int p = blockIdx.x;
     const double* Ap = A + (size_t)p * N * DD;
     const double* bp = b + (size_t)p * N * D;
@@ -132,14 +163,17 @@ fwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* 
 
     // ---- phase 1: the chunk's affine map --------------------------------------------------------
     {
-        const int role = min(r, DD);
+        const int role = min(r, NB);
+        int bi, bj;
+        K::template member<D>(min(role, NB - 1), bi, bj);
         double S[DD], m[D];
 #pragma unroll
-        for (int q = 0; q < DD; ++q) S[q] = (q == role) ? 1.0 : 0.0;
+        for (int q = 0; q < DD; ++q)
+            S[q] = (role < NB && (q == bi * D + bj || (SYM && q == bj * D + bi))) ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < D; ++q) m[q] = (q == role) ? 1.0 : 0.0;
-        integrate(S, m, role == DD ? 1.0 : 0.0, false);
-        if (r <= DD) {
+        integrate(S, m, role == NB ? 1.0 : 0.0, false);
+        if (r <= NB) {
 #pragma unroll
             for (int q = 0; q < D; ++q) ops[c][r][q] = m[q];
 #pragma unroll
@@ -156,13 +190,17 @@ fwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* 
         for (int k = 0; k < K::C; ++k) {
             if (tid < NS) starts[k][e] = x;
             chunk_fence();
-            double acc = ops[k][DD][e];
+            double acc = ops[k][NB][e];
             if (e < D) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) acc = fma(starts[k][j], ops[k][j][e], acc);
             } else {
 #pragma unroll
-                for (int j = 0; j < DD; ++j) acc = fma(starts[k][D + j], ops[k][j][e], acc);
+                for (int q = 0; q < NB; ++q) {
+                    int bi, bj;
+                    K::template member<D>(q, bi, bj);
+                    acc = fma(starts[k][D + bi * D + bj], ops[k][q][e], acc);
+                }
             }
             x = acc;
             chunk_fence();
@@ -180,23 +218,23 @@ fwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* 
     }
 }
 
-template <int D, int METHOD>
-__global__ void __launch_bounds__(SmallChunks::NT, 2)
+template <int D, int METHOD, bool SYM>
+__global__ void __launch_bounds__(256, 2)
 bwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* __restrict__ dEdm,
                              const double* __restrict__ dEdS, const double* __restrict__ jm,
                              const int* __restrict__ obs_flag, const double* __restrict__ jumpS, int jumpS_stride,
                              double dt, const double* __restrict__ lam_last, const double* __restrict__ Psi_last,
                              double* __restrict__ lam_out, double* __restrict__ Psi_out) {
     using T = SmallD<D>;
-    using K = SmallChunks;
-    constexpr int DD = T::DD, NS = D + DD, TS = K::T_BWD;
+    using K = SmallChunksT<SYM>;
+    constexpr int DD = T::DD, NS = D + DD, TS = K::T_BWD, NB = K::nbasis(D);
     // a staged row: A, dEsde/dS, dEsde/dm, the jump of lam, the observation flag (as 0.0 / 1.0)
     constexpr int OG = DD, Og = 2 * DD, OJ = 2 * DD + D, OF = 2 * DD + 2 * D, RW = OF + 1;
-    using Tile = ChunkTile<RW, TS + 1>;                    // rows t, t - 1, .. t - TS
-    __shared__ double ops[K::C][DD + 1][NS];
+    using Tile = ChunkTile<RW, TS + 1, K::ROW>;            // rows t, t - 1, .. t - TS
+    __shared__ double ops[K::C][NB + 1][NS];
     __shared__ double starts[K::C][NS];
     __shared__ double tiles[K::WAVES][2][K::CPW][Tile::TILE];
-    const int tid = threadIdx.x, c = tid >> 4, r = tid & 15;
+    const int tid = threadIdx.x, c = tid / K::ROW, r = tid % K::ROW;
     const int p = blockIdx.x;
     const double* Ap = A + (size_t)p * N * DD;
     const double* gm = dEdm + (size_t)p * N * D;
@@ -281,14 +319,17 @@ bwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* 
     };
 
     {
-        const int role = min(r, DD);
+        const int role = min(r, NB);
+        int bi, bj;
+        K::template member<D>(min(role, NB - 1), bi, bj);
         double X[DD], x[D];
 #pragma unroll
-        for (int q = 0; q < DD; ++q) X[q] = (q == role) ? 1.0 : 0.0;
+        for (int q = 0; q < DD; ++q)
+            X[q] = (role < NB && (q == bi * D + bj || (SYM && q == bj * D + bi))) ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < D; ++q) x[q] = (q == role) ? 1.0 : 0.0;
-        integrate(X, x, role == DD ? 1.0 : 0.0, false);
-        if (r <= DD) {
+        integrate(X, x, role == NB ? 1.0 : 0.0, false);
+        if (r <= NB) {
 #pragma unroll
             for (int q = 0; q < D; ++q) ops[c][r][q] = x[q];
 #pragma unroll
@@ -305,13 +346,17 @@ bwd_scan_small_chunks_kernel(int N, const double* __restrict__ A, const double* 
         for (int k = 0; k < K::C; ++k) {
             if (tid < NS) starts[k][e] = x;
             chunk_fence();
-            double acc = ops[k][DD][e];
+            double acc = ops[k][NB][e];
             if (e < D) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) acc = fma(starts[k][j], ops[k][j][e], acc);
             } else {
 #pragma unroll
-                for (int j = 0; j < DD; ++j) acc = fma(starts[k][D + j], ops[k][j][e], acc);
+                for (int q = 0; q < NB; ++q) {
+                    int bi, bj;
+                    K::template member<D>(q, bi, bj);
+                    acc = fma(starts[k][D + bi * D + bj], ops[k][q][e], acc);
+                }
             }
             x = acc;
             chunk_fence();
