@@ -290,7 +290,11 @@ def main(argv=None):
         if args.backend == "gloo":
             dist.init_process_group("gloo")
         elif force_dist and "MASTER_ADDR" not in os.environ:
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
 
