@@ -42,6 +42,7 @@ KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel", "esde": ESDE_KERNEL,
                 "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
 STREAM_FILE = os.path.join(ROOT, "profiles", "r3_hbm_stream_probe.txt")
+REFERENCE_FILE = os.path.join(ROOT, "profiles", "r3_time_reference.txt")
 # read / write streams of each kernel, as tools/diag/hbm_stream_probe names the mixes
 STREAM_MIX = {"fwd_scan": "1R1W", "esde": "2R1W", "bwd_scan_grad": "3R2W"}
 
@@ -106,6 +107,18 @@ def cpu_share():
     return max(1, min(n, avail))
 
 
+def reference_over_port():
+    """Rate of the reference itself over the rate of the NumPy oracle, all cores busy, as measured where the
+    reference can be imported (tools/time_reference.py at N = 2002; the tracked output is read here).  The
+    oracle vectorises the reference's per-step Python loops, so it is the faster of the two."""
+    try:
+        with open(REFERENCE_FILE) as f:
+            rec = json.loads([ln for ln in f if ln.startswith("{")][-1])
+        return 1.0 / float(rec["port_over_reference_all"])
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 def cpu_baseline(D, dt, seconds_target=12.0):
     """The NumPy oracle (a port of the reference algorithm) on a bounded sample of the same
     workload: one process per core, each with one BLAS thread and its own problem of n time
@@ -123,8 +136,12 @@ def cpu_baseline(D, dt, seconds_target=12.0):
         times = pool.map(_cpu_worker, [(D, dt, n, 100 + c, repeat) for c in range(cores)])
     wall = time.perf_counter() - t0
     rate = float(sum(repeat * n / t for t in times))
+    rop = reference_over_port()
     return dict(value=rate, unit="problem*timesteps/s", cores=cores, kind="port",
                 per_core=rate / cores,
+                # what the reference itself would do on these cores (ratio measured in the build container)
+                reference_over_port=rop, reference_equivalent=None if rop is None else rate * rop,
+                reference_over_port_source=os.path.relpath(REFERENCE_FILE, ROOT),
                 sample=f"{cores} processes x 1 problem x {n} time steps x {repeat} evaluation(s) of the same "
                        f"Lorenz-96 D={D} free energy + gradient, NumPy oracle, 1 BLAS thread each, "
                        f"{max(times):.1f} s of work per process ({wall:.1f} s wall incl. start-up)")
