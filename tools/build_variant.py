@@ -25,7 +25,8 @@ def main():
             continue
         obj = os.path.join(objdir, unit + ".o")
         objs.append(obj)
-        jobs.append([b.hipcc()] + b.FLAGS + extra + ["-c", src, "-o", obj])
+        per_file = [] if os.environ.get("VGPA_VARIANT_NO_EXTRA") else b.EXTRA.get(os.path.basename(src), [])
+        jobs.append([b.hipcc()] + b.FLAGS + per_file + extra + ["-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=4) as pool:
         list(pool.map(lambda c: subprocess.run(c, check=True), jobs))
     subprocess.run([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)

@@ -20,8 +20,8 @@ for _ in range(3):
     en = engine.esde(prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
-dbg.vgpa_debug_l96_stamps.argtypes = [ctypes.c_void_p]
-print("rc", dbg.vgpa_debug_l96_stamps(buf))
+dbg.vgpa_debug_l96_wave_stamps.argtypes = [ctypes.c_void_p]
+print("rc", dbg.vgpa_debug_l96_wave_stamps(buf))
 t = np.array([buf[i] for i in (16, 17, 18, 19, 21, 22, 23, 25, 26, 31)], dtype=np.int64)
 names = ["loads", "cholesky", "ef,base", "G+residuals", "reduce", "W", "dS+dm mfma", "dS store", "stores land"]
 for n, v in zip(names, np.diff(t)): print(f"{n:12s} {v:8d} ticks")

@@ -16,6 +16,7 @@
 // dynamics/sys_lorenz_96_ut.py:238-241 evaluate to (the centre point has z = 0 and
 // the Esde m terms cancel exactly).
 #include "common.h"
+#include "esde_args.h"
 #include "linalg.h"
 
 #include <cmath>
@@ -23,16 +24,9 @@
 
 namespace {
 
-struct EsdeArgs {
-    int P, N, D;
-    const double *A, *b, *m, *S;
-    const double* sig_inv_diag;
-    int sig_stride;
-    const double* theta;
-    int theta_stride;
-    double *Esde_t, *Ef, *Edf, *dEdm, *dEdS, *dth_t, *dSig_t;
-    int* status;
-};
+using vgpa::EsdeArgs;
+using vgpa::readlane_f64;
+using vgpa::wave_lds_fence;
 
 // ---------------------------------------------------------------------------
 // Ornstein-Uhlenbeck and double-well, D == 1: one lane per (problem, step).
@@ -869,41 +863,9 @@ void launch_l96_tiled_h(const EsdeArgs& a, size_t total, hipStream_t st) {
     hipLaunchKernelGGL((esde_l96_ut_tiled_kernel<D, HYPER>), dim3((unsigned)total), dim3(256), lds, st, a);
 }
 
-#include "esde_l96_wave.h"
-
-// The wavefront-per-step kernel takes a (steps x problems) grid; more problems than a grid
-// dimension holds are launched in slices of the problem axis.
-void launch_l96_wave40(const EsdeArgs& a, hipStream_t st) {
-    constexpr int MAXP = 65535;
-#ifdef VGPA_EXPERIMENT_LDS_PAD
-    // occupancy experiments: a larger LDS request per workgroup lowers the number of resident wavefronts
-    static const size_t pad = getenv("VGPA_ESDE_LDS_PAD") ? (size_t)atol(getenv("VGPA_ESDE_LDS_PAD")) : 0;
-    const size_t lds = L96Wave::WG_LDS_BYTES + pad;
-#else
-    const size_t lds = L96Wave::WG_LDS_BYTES;
-#endif
-    const size_t N = (size_t)a.N, D = 40, DD = 1600;
-    for (int p0 = 0; p0 < a.P; p0 += MAXP) {
-        EsdeArgs s = a;
-        s.P = a.P - p0 < MAXP ? a.P - p0 : MAXP;
-        const size_t o = (size_t)p0 * N;
-        s.A += o * DD; s.b += o * D; s.m += o * D; s.S += o * DD;
-        s.sig_inv_diag += (size_t)p0 * a.sig_stride;
-        s.theta += (size_t)p0 * a.theta_stride;
-        s.Esde_t += o; s.Ef += o * D; s.dEdm += o * D; s.dEdS += o * DD;
-        if (s.Edf) s.Edf += o * DD;
-        if (s.dth_t) s.dth_t += o * D;
-        if (s.dSig_t) s.dSig_t += o * D;
-        if (s.status) s.status += o;
-        const dim3 grid((unsigned)((s.N + 1) / 2), (unsigned)s.P);      // two steps per workgroup
-        if (s.dSig_t) hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<true>, grid, dim3(128), lds, st, s);
-        else hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<false>, grid, dim3(128), lds, st, s);
-    }
-}
-
 template <int D>
 void launch_l96_tiled(const EsdeArgs& a, size_t total, hipStream_t st) {
-    if constexpr (D == 40) launch_l96_wave40(a, st);
+    if constexpr (D == 40) vgpa::launch_esde_l96_wave40(a, st);
     else if (a.dSig_t) launch_l96_tiled_h<D, true>(a, total, st);
     else launch_l96_tiled_h<D, false>(a, total, st);
     {

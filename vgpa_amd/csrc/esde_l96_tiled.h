@@ -48,12 +48,6 @@ struct L96Tiled {
     static constexpr int LDS_DOUBLES = 2 * MS + XB + NBLK * NB * NB + 4 * NB * NB + 6 * D + 8;
 };
 
-__device__ inline double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 // 1/sqrt(p) and 1/p: hardware estimate plus Newton refinement.
 __device__ inline double rsqrt_refined(double p) {
     double r = __builtin_amdgcn_rsq(p);
@@ -72,9 +66,6 @@ __device__ inline double rcp_refined(double p) {
     return q;
 }
 
-// Orders LDS traffic between the lanes of one wavefront (no instruction is
-// emitted; it only stops the compiler from moving LDS accesses across it).
-__device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 #ifdef VGPA_STAMPS
 // Diagnostic build only: per-phase cycle counts of one workgroup, lane 0.
