@@ -22,6 +22,8 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // 0 plain, 1 non-temporal stores, 2 non-temporal loads and stores.  Used by the D = 40 scan kernels
 // (measured at 512 problems: separate backward scan 7.6 -> 6.9 ms, forward scan 5.6 -> 5.5 ms, the fused
 // backward scan + gradient unchanged); the Lorenz-96 energy kernel keeps plain accesses (it lost 1.5 %).
+// Only for accesses that cover whole cache lines per wavefront instruction: the 8-byte-per-lane stores of dL/dA written
+// non-temporally raised the fused kernel's HBM write traffic by 8 % (partial lines are not merged), so they stay plain.
 #ifndef VGPA_NT
 #define VGPA_NT 2
 #endif

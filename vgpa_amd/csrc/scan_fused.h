@@ -340,7 +340,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) vgpa::st_once(out + L.g[c][reg], dt * (z[c][reg] - s12));   // core/gradL_Ab.py:170, :176
+                for (int reg = 0; reg < 4; ++reg) out[L.g[c][reg]] = dt * (z[c][reg] - s12);   // core/gradL_Ab.py:170, :176
             M40F_STAMP(3);
         }
     } else {
