@@ -899,3 +899,30 @@ def test_small_dimension_scans_parallel_in_time_vs_sequential_oracle(D, N, metho
     lr, Pr = orc.bwd_scan(A[1], gm[1], gSs[1], jm[1], jSs, dt, method, lam_last=lamT[1], Psi_last=PsiTs[1])
     for got, want in ((m4[1], mr), (S4[1], Sr), (l4[1], lr), (P4[1], Pr)):
         assert relerr(got.cpu().numpy(), want) <= 1e-11
+
+
+def test_cached_problem_follows_values_edited_in_place():
+    """varFreeEnergy keeps the last device problem while the values it was built from are unchanged; a driver that
+    edits sde_struct in place (theta in the parameter-estimation loop, lorenz-63-parameter-estimation.py:215) must
+    get the evaluation for the new values; the arrays copied out on the second stream are those of a plain copy."""
+    from vgpa_amd.core.varFreeEnergy import varFreeEnergy
+    from vgpa_amd.core import _facade
+    g = load_golden("sys_l63_ut.npz")
+    sde = sde_from_golden(g, "EULER")
+    sde["theta"] = np.array(sde["theta"], dtype=np.float64, copy=True)
+    m0, S0 = initial_moments(g)
+    mParam = dict(m0=m0, S0=S0, fun=_dyn("l63_ut").energy_mode, sde_struct=sde)
+    F0 = varFreeEnergy(g["Ab"], mParam)
+    p0 = _facade._problem_cache[2]
+    assert abs(F0 - float(g["EULER.F"])) <= TOL * abs(float(g["EULER.F"]))
+    for key, gk in (("mt", "m"), ("St", "S"), ("lamt", "lam"), ("Psit", "Psi"), ("Efx", "Ef"), ("Edf", "Edf")):
+        assert relerr(mParam[key], g[f"EULER.{gk}"]) <= TOL, key
+    assert varFreeEnergy(g["Ab"], mParam) == F0 and _facade._problem_cache[2] is p0
+    sde["theta"] *= 1.05                                   # in place: same dictionary, same array object
+    F1 = varFreeEnergy(g["Ab"], mParam)
+    assert _facade._problem_cache[2] is not p0
+    ref = orc.evaluate("l63_ut", g["Ab"], m0, S0, sde)
+    assert abs(F1 - ref["F"]) <= TOL * abs(ref["F"]) and abs(F1 - F0) > 1e-6 * abs(F0)
+    m0b = m0 + 0.01
+    F2 = varFreeEnergy(g["Ab"], dict(mParam, m0=m0b))
+    assert abs(F2 - orc.evaluate("l63_ut", g["Ab"], m0b, S0, sde)["F"]) <= TOL * abs(F2)

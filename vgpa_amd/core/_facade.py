@@ -67,6 +67,74 @@ def to_host(tensors):
     return [h.numpy() for h in host]
 
 
+class AsyncPublisher:
+    """Copies arrays to page-locked host memory on a stream of its own while the evaluation that
+    produces them is still running: ``ready(name, tensor)`` (the ``on_ready`` hook of
+    engine.free_energy) makes the copy stream wait for what the compute stream has enqueued so
+    far and queues the copy behind it; ``collect()`` waits for the copies and returns the NumPy
+    arrays by name.  The tensors must stay referenced until collect() has returned (the State of
+    the evaluation holds them)."""
+    _streams = {}
+
+    def __init__(self):
+        import torch
+        dev = torch.cuda.current_device()
+        if dev not in AsyncPublisher._streams:
+            AsyncPublisher._streams[dev] = torch.cuda.Stream(device=dev)
+        self._stream = AsyncPublisher._streams[dev]
+        self._host = {}
+
+    def ready(self, name, t):
+        import torch
+        if t is None:
+            return
+        done = torch.cuda.Event()
+        done.record()                                   # on the compute stream: everything enqueued so far
+        src = t[0]
+        h = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(done)
+            h.copy_(src, non_blocking=True)
+        self._host[name] = h
+
+    def collect(self):
+        self._stream.synchronize()
+        return {k: h.numpy() for k, h in self._host.items()}
+
+
+# ---------------------------------------------------------------------------
+# make_problem uploads a dozen small arrays and inverts Sigma and R on the host: about half a
+# millisecond per call, paid by every varFreeEnergy of an optimiser run whose sde_struct never
+# changes.  The last problem is kept, keyed on the VALUES it was built from (the reference's drivers
+# edit sde_struct in place, e.g. theta in the parameter-estimation loop).
+# ---------------------------------------------------------------------------
+_problem_cache = None
+
+
+def _problem_key(system, sde, m0, S0, fun):
+    def raw(x):
+        a = np.asarray(x)
+        return (a.dtype.str, a.shape, a.tobytes())
+    px0 = sde["px0"]
+    return (system, id(fun) if system < 0 else None, int(sde["N"]), int(sde["D"]), float(sde["dt"]),
+            str(sde.get("ode_method", "EULER")).upper(),
+            tuple(raw(sde[k]) if k in sde else None for k in ("Sig", "theta", "Rig", "H", "obsX", "obsY")),
+            raw(px0["mu0"]), raw(px0["tau0"]), raw(m0), raw(S0))
+
+
+def cached_problem(system, sde, m0, S0, fun=None):
+    """engine.make_problem(system, sde, m0, S0, P=1, fun=fun), re-used while every value it depends on is unchanged."""
+    global _problem_cache
+    import torch
+    key = _problem_key(system, sde, m0, S0, fun)
+    c = _problem_cache
+    if c is not None and c[0] == key and c[1] == torch.cuda.current_device():
+        return c[2]
+    prob = engine.make_problem(system, sde, m0, S0, P=1, fun=fun)
+    _problem_cache = (key, torch.cuda.current_device(), prob)
+    return prob
+
+
 def host_vec(t, D):
     """Device (1,N,D) / (1,N) -> NumPy (N,D) / (N,1)."""
     a = to_host([t[0]])[0]

@@ -7,28 +7,35 @@ from . import _facade
 __all__ = ["varFreeEnergy", "finite_difference_batched"]
 
 
-def _evaluate(Ab, mParam, want_hyper=False):
+def _evaluate(Ab, mParam, want_hyper=False, on_ready=None):
     """Run the device pipeline for one problem; returns (problem, A, b, state)."""
     sde = mParam["sde_struct"]
     N, D = int(sde["N"]), int(sde["D"])
     A, b = _facade.unpack_Ab(Ab, N, D)
     fun = mParam["fun"]
     system = _facade.system_of(fun)
-    prob = engine.make_problem(system, sde, mParam["m0"], mParam["S0"], P=1,
-                               fun=fun if system < 0 else None)
+    prob = _facade.cached_problem(system, sde, mParam["m0"], mParam["S0"], fun=fun if system < 0 else None)
     Ad = _facade.dev_batch1(A, D, "m")
     bd = _facade.dev_batch1(b, D, "v")
-    st = engine.free_energy(prob, Ad, bd, want_hyper=want_hyper)
+    st = engine.free_energy(prob, Ad, bd, want_hyper=want_hyper, on_ready=on_ready)
     engine.check_status(st.status)
     return prob, Ad, bd, st
 
 
-def _publish(mParam, st, D):
+_PUBLISHED = (("mt", "m"), ("St", "S"), ("Efx", "Ef"), ("Edf", "Edf"), ("lamt", "lam"), ("Psit", "Psi"))
+
+
+def _publish(mParam, st, D, host=None):
     """The side effects of the reference (core/varFreeEnergy.py:84-104): host arrays
-    that drivers index and deep-copy."""
-    keys = ("mt", "St", "Efx", "Edf", "lamt", "Psit")
-    host = _facade.to_host([t[0] for t in (st.m, st.S, st.Ef, st.Edf, st.lam, st.Psi)])
-    for k, a in zip(keys, host):
+    that drivers index and deep-copy.  ``host``: arrays already copied out by name
+    (_facade.AsyncPublisher); what is missing there is copied now."""
+    host = dict(host or {})
+    missing = [(k, n) for k, n in _PUBLISHED if n not in host]
+    if missing:
+        got = _facade.to_host([getattr(st, n)[0] for _, n in missing])
+        host.update({n: a for (_, n), a in zip(missing, got)})
+    for k, n in _PUBLISHED:
+        a = host[n]
         mParam[k] = a.reshape(-1, 1) if D == 1 else a
 
 
@@ -39,8 +46,10 @@ def varFreeEnergy(Ab, mParam):
     receives 'mt', 'St', 'Efx', 'Edf', 'lamt', 'Psit' as NumPy arrays.  Returns a
     Python float (core/varFreeEnergy.py:111).
     """
-    prob, Ad, bd, st = _evaluate(Ab, mParam)
-    _publish(mParam, st, prob.D)
+    # the six arrays are copied to the host on a second stream while the later kernels still run
+    pub = _facade.AsyncPublisher()
+    prob, Ad, bd, st = _evaluate(Ab, mParam, on_ready=pub.ready)
+    _publish(mParam, st, prob.D, pub.collect())
     if prob.system >= 0:
         _facade.remember_published(mParam, prob, Ad, bd, st)
     return float(st.F[0].item())

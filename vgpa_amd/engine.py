@@ -550,23 +550,34 @@ class State:
     dSig: Optional[torch.Tensor] = None
 
 
-def free_energy(prob, A, b, want_hyper=False, want_edf=True, need_adjoint=True):
+def free_energy(prob, A, b, want_hyper=False, want_edf=True, need_adjoint=True, on_ready=None):
     """core/varFreeEnergy.py:80-111 for a batch: returns a State with F (P,).
     ``want_edf=False`` (Lorenz systems) skips the dense <df/dx> array; ``gradient``
     then lets the assembly kernel derive it from the mean.  ``need_adjoint=False``
-    skips the backward scan (lam, Psi are None): enough when only F is wanted."""
+    skips the backward scan (lam, Psi are None): enough when only F is wanted.
+    ``on_ready(name, tensor)`` is called for m, S, Ef, Edf, lam, Psi as soon as the kernel that
+    produces the array has been enqueued (a caller can start copying it out on another stream
+    while the rest of the evaluation runs)."""
+    ready = on_ready if on_ready is not None else (lambda name, t: None)
     m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
+    ready("m", m)
+    ready("S", S)
     Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
     if prob.system < 0:
         en = _host_energy(prob, A, b, m, S)
     else:
         en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w,
                           prob.dt, want_hyper, want_edf=want_edf or prob.D == 1)
+    ready("Ef", en["Ef"])
+    if en["Edf"] is not None:
+        ready("Edf", en["Edf"])
     sym = prob.sym_jump and prob.system >= 0 and esde_output_is_symmetric(prob.system, prob.D)
     lam = Psi = None
     if need_adjoint:
         lam, Psi = bwd_scan(prob.method, A, en["dEdm"], en["dEdS"], dEobs_dm, prob.dt,
                             obs_flag=prob.obs_flag, jumpS=jumpS, symmetric=sym)
+        ready("lam", lam)
+        ready("Psi", Psi)
     KL0 = kl0(prob)
     F = KL0 + Eobs + en["Esde"]
     return State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"],
