@@ -85,6 +85,15 @@ extern "C" {
                                     written (19 % of its memory traffic).  For callers
                                     that only want F and the gradient, e.g. an optimiser. */
 
+#define VGPA_SCAN_PACKED 8       /* the symmetric matrices of every time row -- S_out of
+                                    vgpa_fwd_scan; S, dEsde_dS and Psi_out of vgpa_bwd_scan_grad
+                                    -- are in the packed layout described at vgpa_sym_pack
+                                    (1152 doubles a row instead of 1600).  Euler method, D = 40,
+                                    with VGPA_SCAN_SYMMETRIC; vgpa_bwd_scan_grad only where
+                                    vgpa_bwd_scan_grad_is_fused() holds.  A, dL/dA, the vectors,
+                                    S0, Sigma, the jumps and the terminal state stay dense.
+                                    Anything else: VGPA_EUNSUPPORTED.                          */
+
 /* largest state dimension the n-D kernels accept */
 #define VGPA_MAX_D 60
 
@@ -227,6 +236,50 @@ int vgpa_obs_terms(int P, int N, int D, int M, int d,
                    const double* H, const double* Ri, const double* Qi,
                    double logconst, double* work,
                    double* Eobs, double* dEobs_dm, double* jumpS, void* stream);
+
+/*
+ * Packed symmetric matrices (D = 40 only).  A symmetric 40 x 40 matrix is kept as the rows of its
+ * lower BLOCK triangle with 16 x 16 blocks: row r holds its first 16 (r / 16 + 1) entries, i.e.
+ * everything left of and inside its diagonal block (the diagonal blocks whole, both triangles):
+ *     rows  0 .. 15   16 doubles each, at  16 r
+ *     rows 16 .. 31   32 doubles each, at 256 + 32 (r - 16)
+ *     rows 32 .. 39   48 doubles each, at 768 + 48 (r - 32)   (columns 40 .. 47: padding, never
+ *                                                              read or written)
+ * 1152 doubles = vgpa_sym_packed_size(40) instead of 1600, every row a whole number of 128-byte
+ * lines.  The Euler kernels of the Lorenz-96 path read and write S, dEsde_dS and Psi in this form
+ * when asked to (VGPA_SCAN_PACKED, vgpa_esde_l96_ut_packed, vgpa_obs_terms_packed): 16 % less
+ * memory traffic per evaluation.  It has no counterpart in the reference; it is an option for
+ * callers that consume F and the gradient (an optimiser) rather than the matrices themselves.
+ *   vgpa_sym_pack    dense (count,40,40) -> packed (count,1152); reads the kept entries only
+ *   vgpa_sym_unpack  packed (count,1152) -> dense (count,40,40), mirrored above the block diagonal
+ *   vgpa_sym_packed_size(D)  1152 for D == 40, -1 otherwise
+ */
+int vgpa_sym_pack(long long count, int D, const double* dense, double* packed, void* stream);
+int vgpa_sym_unpack(long long count, int D, const double* packed, double* dense, void* stream);
+int vgpa_sym_packed_size(int D);
+
+/*
+ * vgpa_esde_l96_ut (dynamics/sys_lorenz_96_ut.py:131) at D = 40 on packed symmetric matrices:
+ * S_packed (P,N,1152) in, dEsde_dS_packed (P,N,1152) out, no Edf; the other arguments and results
+ * as vgpa_esde_l96_ut.  Results are those of the dense call bit for bit when S is bitwise symmetric.
+ */
+int vgpa_esde_l96_ut_packed(int P, int N,
+                            const double* A, const double* b, const double* m, const double* S_packed,
+                            const double* sig_inv_diag, int sig_stride,
+                            const double* theta, int theta_stride,
+                            double* Esde_t, double* Ef, double* dEsde_dm, double* dEsde_dS_packed,
+                            double* dth_t, double* dSig_t, int* status, void* stream);
+
+/*
+ * vgpa_obs_terms (core/likelihood.py@108-179) at D = 40 with S_packed (P,N,1152); it reads the
+ * diagonal of S only.  Other arguments and results as vgpa_obs_terms.
+ */
+int vgpa_obs_terms_packed(int P, int N, int M, int d,
+                          const double* m, const double* S_packed,
+                          const int* obs_idx, const double* obsY, int obsY_stride,
+                          const double* H, const double* Ri, const double* Qi,
+                          double logconst, double* work,
+                          double* Eobs, double* dEobs_dm, double* jumpS, void* stream);
 
 /*
  * vgpa_obs_terms for callers that cannot allocate device memory (code under HIP graph

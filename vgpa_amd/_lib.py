@@ -29,6 +29,8 @@ GRAD_OUTER, GRAD_SIGINV_DIAG = 1, 2
 SCAN_SYMMETRIC = 1
 SCAN_STATE_SYMMETRIC = 2
 SCAN_PSI_ROW0 = 4
+SCAN_PACKED = 8
+SYM_PACKED_40 = 1152     # doubles of a packed symmetric 40 x 40 matrix (vgpa_sym_packed_size(40))
 MAX_D = 60
 OBS_STATIC_MAX = 1 << 17
 
@@ -51,6 +53,12 @@ SIGNATURES = {
     "vgpa_esde_l63": _ESDE_ARGS,
     "vgpa_esde_l63_ut": _ESDE_ARGS,
     "vgpa_esde_l96_ut": _ESDE_ARGS,
+    "vgpa_esde_l96_ut_packed": [_c_int, _c_int] + [_ptr] * 4 + [_ptr, _c_int, _ptr, _c_int] + [_ptr] * 7 + [_ptr],
+    "vgpa_obs_terms_packed": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
+                              _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "vgpa_sym_pack": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr],
+    "vgpa_sym_unpack": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr],
+    "vgpa_sym_packed_size": [_c_int],
     "vgpa_reduce_energy": [_c_int, _c_int, _c_int, _ptr, _ptr, _c_dbl, _ptr, _ptr],
     "vgpa_obs_terms": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
                        _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr],

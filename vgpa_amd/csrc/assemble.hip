@@ -1,6 +1,7 @@
 // Time reductions, observation terms, initial-state KL energy and the assembly of
 // dL/dA, dL/db, gfx950.
 #include "common.h"
+#include "sym_rows.h"
 #include <mutex>
 #include "linalg.h"
 
@@ -90,7 +91,8 @@ __global__ void __launch_bounds__(256)
 obs_terms_nd_lds_kernel(int N, int D, int M, const double* __restrict__ m, const double* __restrict__ S,
                         const int* __restrict__ obs_idx, const double* __restrict__ obsY, int obsY_stride,
                         const double* __restrict__ H, const double* __restrict__ Ri, const double* __restrict__ Qi,
-                        double* __restrict__ work, double* __restrict__ dEobs_dm) {
+                        double* __restrict__ work, double* __restrict__ dEobs_dm, int packed) {
+    // packed (D = 40): S in the packed symmetric layout of sym_rows.h; only its diagonal is read here
     extern __shared__ double lds[];
     const int LD = D + 1, MS = D * LD;
     double* Hs = lds;
@@ -107,7 +109,8 @@ obs_terms_nd_lds_kernel(int N, int D, int M, const double* __restrict__ m, const
     }
     __syncthreads();
     const int p = blockIdx.y;
-    const size_t DD = (size_t)D * D;
+    const size_t DD = packed ? (size_t)vgpa::SymRows40::SIZE : (size_t)D * D;
+    const size_t sdiag = packed ? (size_t)(vgpa::SymRows40::row_offset(min(l, D - 1)) + l) : (size_t)l * D + l;
     const double* Y = obsY + (size_t)p * obsY_stride;
     for (int n = blockIdx.x * OBS_PER_WG + w; n < M && n < (blockIdx.x + 1) * OBS_PER_WG; n += 4) {
         const int tn = obs_idx[n];
@@ -126,7 +129,7 @@ obs_terms_nd_lds_kernel(int N, int D, int M, const double* __restrict__ m, const
                 t = fma(Rs[l * LD + j], Wv[j], t);
             }
             Tv[l] = t;
-            e_l = z * z + Rs[l * LD + l] * S[((size_t)p * N + tn) * DD + (size_t)l * D + l];
+            e_l = z * z + Rs[l * LD + l] * S[((size_t)p * N + tn) * DD + sdiag];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (l < D) {
@@ -663,7 +666,7 @@ __global__ void zero_fill_kernel(double* __restrict__ x, size_t n) {
 int obs_terms_impl(const char* who, int P, int N, int D, int M, int d, const double* m, const double* S,
                    const int* obs_idx, const double* obsY, int obsY_stride, const double* H, const double* Ri,
                    const double* Qi, double logconst, double* work, double* Eobs, double* dEobs_dm, double* jumpS,
-                   hipStream_t st) {
+                   hipStream_t st, bool packed = false) {
     {
         const size_t n = (size_t)P * N * D;
         const size_t want = (n + 255) / 256;
@@ -686,7 +689,7 @@ int obs_terms_impl(const char* who, int P, int N, int D, int M, int d, const dou
         } else if (M > 0 && sizeof(double) * (3 * D * (D + 1) + 8 * D) <= 64 * 1024) {
             const size_t lds2 = sizeof(double) * (3 * D * (D + 1) + 8 * D);
             hipLaunchKernelGGL(obs_terms_nd_lds_kernel, dim3((M + OBS_PER_WG - 1) / OBS_PER_WG, P), dim3(256), lds2, st, N, D,
-                               M, m, S, obs_idx, obsY, obsY_stride, H, Ri, Qi, work, dEobs_dm);
+                               M, m, S, obs_idx, obsY, obsY_stride, H, Ri, Qi, work, dEobs_dm, packed ? 1 : 0);
         } else if (M > 0) {
             hipLaunchKernelGGL(obs_terms_nd_kernel, dim3(M, P), dim3(64), lds, st, N, D, M, m, S, obs_idx, obsY,
                                obsY_stride, H, Ri, Qi, work, dEobs_dm);
@@ -713,6 +716,22 @@ extern "C" int vgpa_obs_terms(int P, int N, int D, int M, int d, const double* m
     if (P == 0) return VGPA_OK;
     return obs_terms_impl("vgpa_obs_terms", P, N, D, M, d, m, S, obs_idx, obsY, obsY_stride, H, Ri, Qi, logconst, work,
                           Eobs, dEobs_dm, jumpS, vgpa::as_stream(stream));
+}
+
+// vgpa_obs_terms with S in the packed symmetric layout (D = 40): the kernel reads the diagonal of S only.
+extern "C" int vgpa_obs_terms_packed(int P, int N, int M, int d, const double* m, const double* S_packed,
+                                     const int* obs_idx, const double* obsY, int obsY_stride, const double* H,
+                                     const double* Ri, const double* Qi, double logconst, double* work, double* Eobs,
+                                     double* dEobs_dm, double* jumpS, void* stream) {
+    constexpr int D = 40;
+    VGPA_REQUIRE(P >= 0 && N >= 1 && M >= 0, "vgpa_obs_terms_packed: bad sizes P=%d N=%d M=%d", P, N, M);
+    VGPA_REQUIRE(d == D, "vgpa_obs_terms_packed: observation dimension d=%d must equal D=40", d);
+    VGPA_REQUIRE(m && S_packed && (M == 0 || (obs_idx && obsY)) && H && Ri && Qi && work && Eobs && dEobs_dm,
+                 "vgpa_obs_terms_packed: null pointer argument");
+    VGPA_REQUIRE(obsY_stride == 0 || obsY_stride == M * d, "vgpa_obs_terms_packed: obsY_stride must be 0 or M*d");
+    if (P == 0) return VGPA_OK;
+    return obs_terms_impl("vgpa_obs_terms_packed", P, N, D, M, d, m, S_packed, obs_idx, obsY, obsY_stride, H, Ri, Qi,
+                          logconst, work, Eobs, dEobs_dm, jumpS, vgpa::as_stream(stream), true);
 }
 
 // ---------------------------------------------------------------------------

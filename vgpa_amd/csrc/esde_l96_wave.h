@@ -272,10 +272,14 @@ __device__ __forceinline__ void wv_ring(int l, int& f1, int& b1, int& b2) {
     b2 = (l <= 1) ? l + L96Wave::D - 2 : l - 2;
 }
 
-template <bool HYPER>
+// PACKED: S(t) is read and dEsde/dS(t) is written in the packed symmetric layout of sym_rows.h
+// (1152 doubles a step).  The kernel only ever reads the lower block triangle of S with whole
+// diagonal blocks, which is what that layout holds, and forms only those tiles of dEsde/dS.
+template <bool HYPER, bool PACKED>
 __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     using C = L96Wave;
     constexpr int D = C::D, LD = C::LD, DD = C::DD, VL = C::VL;
+    constexpr int SS = PACKED ? vgpa::SymRows40::SIZE : DD;      // doubles per symmetric matrix in memory
     extern __shared__ double lds_all[];
     // Two wavefronts, two consecutive steps, each with its own LDS image.  They only meet at the three
     // diagonal blocks of the factorisation, which ONE of them factors for both (the halves of that
@@ -323,7 +327,36 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     // Sixteen-byte pieces: instruction i moves rows 3 i .. 3 i + 2, lane l (< 60) the piece
     // (row 3 i + l / 20, column pair l % 20); every address is one per-lane base plus a
     // compile-time offset.  Lanes 60..63 repeat lane 59.
-    {
+    if constexpr (PACKED) {
+        // nine instructions: rows 0..15 eight at a time (8 pieces a row), rows 16..31 four at a time
+        // (16 pieces), rows 32..39 three at a time on 60 lanes (20 pieces without the padding); the last
+        // one has rows 38, 39 only and the lanes of its third row repeat row 39
+        const double2* src = reinterpret_cast<const double2*>(a.S + e * SS);
+        const int l60 = min(lane, 59);
+        const int lr = (l60 >= 20) + (l60 >= 40), lc = l60 - 20 * lr;
+        const double2* sA = src + lane;
+        const double2* sB = src + 128 + lane;
+        const double2* sC = src + 384 + 24 * lr + lc;
+        double* dA = buf + (lane >> 3) * LD + 2 * (lane & 7);
+        double* dB = buf + (16 + (lane >> 4)) * LD + 2 * (lane & 15);
+        double* dC = buf + (32 + lr) * LD + 2 * lc;
+        const int back = lr == 2 ? 1 : 0;
+        double2 v[9];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v[i] = sA[64 * i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[2 + i] = sB[64 * i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v[6 + i] = sC[72 * i];
+        v[8] = sC[72 * 2 - 24 * back];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<double2*>(dA + 8 * i * LD) = make_double2(c2 * v[i].x, c2 * v[i].y);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(dB + 4 * i * LD) = make_double2(c2 * v[2 + i].x, c2 * v[2 + i].y);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<double2*>(dC + 3 * i * LD) = make_double2(c2 * v[6 + i].x, c2 * v[6 + i].y);
+        *reinterpret_cast<double2*>(dC + (6 - back) * LD) = make_double2(c2 * v[8].x, c2 * v[8].y);
+    } else {
         const int l60 = min(lane, 59);
         const int lr = (l60 >= 20) + (l60 >= 40), lc = l60 - 20 * lr;
         const double2* src = reinterpret_cast<const double2*>(a.S + e * DD) + lr * (D / 2) + lc;
@@ -371,7 +404,10 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
         const int l = lv;
         int f1, b1, b2;
         wv_ring(l, f1, b1, b2);
-        Cxx = (buf[f1 * LD + b1] - buf[b2 * LD + b1]) * (1.0 / c2);
+        // packed: entries above the block diagonal are not in LDS, their mirror images are
+        const int r1 = PACKED ? max(f1, b1) : f1, c1 = PACKED ? min(f1, b1) : b1;
+        const int r2 = PACKED ? max(b2, b1) : b2, c2i = PACKED ? min(b2, b1) : b1;
+        Cxx = (buf[r1 * LD + c1] - buf[r2 * LD + c2i]) * (1.0 / c2);
     }
     wave_lds_fence();
 
@@ -579,7 +615,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             a.dEdm[e * D + lane] = nan;
             if (a.dSig_t) a.dSig_t[e * D + lane] = nan;
         }
-        for (int q = lane; q < DD; q += 64) a.dEdS[e * DD + q] = nan;
+        for (int q = lane; q < SS; q += 64) a.dEdS[e * SS + q] = nan;
         return;
     }
 
@@ -877,7 +913,32 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             if (g4 == 0 && 16 * t + pi < D) a.dEdm[e * D + 16 * t + pi] = 0.5 * w1 * c2 * y;
         }
     WV_STAMP(25);
-        double* Gd = a.dEdS + e * DD;
+        double* Gd = a.dEdS + e * SS;
+        if constexpr (PACKED) {
+            // Row 16 i + x of the packed layout starts at base_i + width_i x.  Diagonal tiles go out
+            // transposed like below (four consecutive doubles of row 16 i + c16); a tile below the diagonal
+            // is stored once, as the rows it is: four 8-byte stores, each a full 128-byte line per
+            // lane group.
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                constexpr int BASE[3] = {0, 256, 768};
+                const int base = BASE[i], width = 16 * (i + 1);
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    if ((i < 2 || g4 < 2) && (j < 2 || c16 < 8)) {
+                        if (j == i) {
+                            double* dt_ = Gd + base + width * c16 + 16 * i + 4 * g4;
+                            *reinterpret_cast<double2*>(dt_) = make_double2(acc[i][j][0], acc[i][j][1]);
+                            *reinterpret_cast<double2*>(dt_ + 2) = make_double2(acc[i][j][2], acc[i][j][3]);
+                        } else {
+                            double* dst = Gd + base + width * 4 * g4 + 16 * j + c16;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) dst[q * width] = acc[i][j][q];
+                        }
+                    }
+                }
+            }
+        } else {
             // The result is bitwise symmetric, so only the tiles on and below the diagonal are formed.
             // A lane holds rows 4 g4 .. 4 g4 + 3 of one column of a tile: stored transposed, that is
             // four consecutive doubles of row (16 j + c16) -- two 16-byte stores; tiles below the
@@ -897,6 +958,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
                         }
                     }
                 }
+        }
     }
     WV_STAMP(26);
 #ifdef VGPA_STAMPS

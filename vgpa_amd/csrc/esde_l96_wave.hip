@@ -5,6 +5,7 @@
 // kernels of esde.hip 30-56 registers, so it is applied to this file alone (vgpa_amd/build.py).
 #include "common.h"
 #include "esde_args.h"
+#include "sym_rows.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -35,22 +36,27 @@ void vgpa::launch_esde_l96_wave40(const EsdeArgs& a, hipStream_t st) {
 #else
     const size_t lds = L96Wave::WG_LDS_BYTES;
 #endif
-    const size_t N = (size_t)a.N, D = 40, DD = 1600;
+    const size_t N = (size_t)a.N, D = 40, DD = 1600, SS = a.packed ? vgpa::SymRows40::SIZE : DD;
     for (int p0 = 0; p0 < a.P; p0 += MAXP) {
         EsdeArgs s = a;
         s.P = a.P - p0 < MAXP ? a.P - p0 : MAXP;
         const size_t o = (size_t)p0 * N;
-        s.A += o * DD; s.b += o * D; s.m += o * D; s.S += o * DD;
+        s.A += o * DD; s.b += o * D; s.m += o * D; s.S += o * SS;
         s.sig_inv_diag += (size_t)p0 * a.sig_stride;
         s.theta += (size_t)p0 * a.theta_stride;
-        s.Esde_t += o; s.Ef += o * D; s.dEdm += o * D; s.dEdS += o * DD;
+        s.Esde_t += o; s.Ef += o * D; s.dEdm += o * D; s.dEdS += o * SS;
         if (s.Edf) s.Edf += o * DD;
         if (s.dth_t) s.dth_t += o * D;
         if (s.dSig_t) s.dSig_t += o * D;
         if (s.status) s.status += o;
         const dim3 grid((unsigned)((s.N + 1) / 2), (unsigned)s.P);      // two steps per workgroup
-        if (s.dSig_t) hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<true>, grid, dim3(128), lds, st, s);
-        else hipLaunchKernelGGL(esde_l96_ut_wave40_kernel<false>, grid, dim3(128), lds, st, s);
+        if (s.packed) {
+            if (s.dSig_t) hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<true, true>), grid, dim3(128), lds, st, s);
+            else hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<false, true>), grid, dim3(128), lds, st, s);
+        } else {
+            if (s.dSig_t) hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<true, false>), grid, dim3(128), lds, st, s);
+            else hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<false, false>), grid, dim3(128), lds, st, s);
+        }
     }
 }
 

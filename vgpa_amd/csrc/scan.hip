@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "sym_rows.h"
 
 namespace {
 
@@ -860,8 +861,8 @@ void launch_fwd(int P, int N, int D, const double* A, const double* b, const dou
     }
     if constexpr (METHOD == VGPA_EULER && DT == 40 && SYM) {
         const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
-        allow_lds(fwd_euler_sym_mfma40_kernel, lds);
-        hipLaunchKernelGGL(fwd_euler_sym_mfma40_kernel, dim3(P), dim3(M40::NT), lds, st, N, A, b, m0, S0, Sigma,
+        allow_lds(fwd_euler_sym_mfma40_kernel<false>, lds);
+        hipLaunchKernelGGL(fwd_euler_sym_mfma40_kernel<false>, dim3(P), dim3(M40::NT), lds, st, N, A, b, m0, S0, Sigma,
                            sigma_stride, dt, m_out, S_out);
         return;
     }
@@ -944,6 +945,17 @@ extern "C" int vgpa_fwd_scan(int method, int P, int N, int D, const double* A, c
         return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_fwd_scan: D=%d with method %d needs more than the 160 KB of LDS of a compute unit", D, method);
     g_lds_refused = false;
     hipStream_t st = vgpa::as_stream(stream);
+    if (flags & VGPA_SCAN_PACKED) {
+        if (!(method == VGPA_EULER && D == 40 && (flags & VGPA_SCAN_SYMMETRIC)))
+            return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_fwd_scan: VGPA_SCAN_PACKED needs the Euler method, D == 40 and "
+                              "VGPA_SCAN_SYMMETRIC (got method %d, D=%d, flags %d)", method, D, flags);
+        const size_t lds = sizeof(double) * M40::LDS_DOUBLES;
+        allow_lds(fwd_euler_sym_mfma40_kernel<true>, lds);
+        if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_fwd_scan: the LDS size this launch needs was refused");
+        hipLaunchKernelGGL(fwd_euler_sym_mfma40_kernel<true>, dim3(P), dim3(M40::NT), lds, st, N, A, b, m0, S0, Sigma,
+                           sigma_stride, dt, m_out, S_out);
+        return vgpa::check_launch("vgpa_fwd_scan");
+    }
     if (D == 1) {
         // one workgroup per problem, the steps as a parallel prefix computation
         const size_t lds = Prefix1D::fwd_lds_bytes();
@@ -1026,6 +1038,10 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
                  "vgpa_bwd_scan_grad: null pointer argument");
     const bool fused = vgpa_bwd_scan_grad_is_fused(method, P, D, scan_flags, grad_flags, dEobs_dS != nullptr,
                                                    Edf != nullptr, edf_system) != 0;
+    const bool packed = (scan_flags & VGPA_SCAN_PACKED) != 0;
+    if (packed && !(fused && method == VGPA_EULER))
+        return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan_grad: VGPA_SCAN_PACKED is accepted only with the Euler method "
+                          "where vgpa_bwd_scan_grad_is_fused() holds");
     if (!fused && (scan_flags & VGPA_SCAN_PSI_ROW0))
         return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan_grad: VGPA_SCAN_PSI_ROW0 is accepted only where "
                           "vgpa_bwd_scan_grad_is_fused() holds (the assembly kernel needs every row of Psi)");
@@ -1058,13 +1074,72 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
         return vgpa::check_launch("vgpa_bwd_scan_grad");
     }
     const size_t lds = sizeof(double) * M40F::LDS_DOUBLES;
-    allow_lds(bwd_grad_euler_sym_mfma40_kernel, lds);
+    auto launch = [&](auto kernel) {
+        allow_lds(kernel, lds);
+        if (g_lds_refused) return;
+        hipLaunchKernelGGL(kernel, dim3(P), dim3(M40F::NT), lds, vgpa::as_stream(stream), N, A, b, m, S, dEsde_dm, dEsde_dS,
+                           dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt, lam_last, Psi_last, lam_out,
+                           Psi_out, psi_all, gLA, gLb);
+    };
+    if (packed) launch(bwd_grad_euler_sym_mfma40_kernel<true>);
+    else launch(bwd_grad_euler_sym_mfma40_kernel<false>);
     if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan_grad: the LDS size this launch needs was refused");
-    hipLaunchKernelGGL(bwd_grad_euler_sym_mfma40_kernel, dim3(P), dim3(M40F::NT), lds, vgpa::as_stream(stream), N, A, b, m,
-                       S, dEsde_dm, dEsde_dS, dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt,
-                       lam_last, Psi_last, lam_out, Psi_out, psi_all, gLA, gLb);
     return vgpa::check_launch("vgpa_bwd_scan_grad");
 }
+
+namespace {
+
+// one thread per 16-byte piece of a packed matrix
+template <bool TO_PACKED>
+__global__ void __launch_bounds__(256) sym_rows_convert_kernel(size_t count, const double* __restrict__ src,
+                                                               double* __restrict__ dst) {
+    using L = vgpa::SymRows40;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count * L::PIECES) return;
+    const size_t mtx = i / L::PIECES;
+    const int e = 2 * (int)(i % L::PIECES);
+    int r, c;
+    L::coords(e, r, c);
+    if (c >= L::D) return;                                   // padding
+    const double* dense_in = src + mtx * (L::D * L::D);
+    double* dense_out = dst + mtx * (L::D * L::D);
+    if (TO_PACKED) {
+        *reinterpret_cast<double2*>(dst + mtx * L::SIZE + e) = *reinterpret_cast<const double2*>(dense_in + r * L::D + c);
+    } else {
+        const double2 v = *reinterpret_cast<const double2*>(src + mtx * L::SIZE + e);
+        *reinterpret_cast<double2*>(dense_out + r * L::D + c) = v;
+        if (c < 16 * (r / 16)) {                             // left of the diagonal block: also the mirror image
+            dense_out[c * L::D + r] = v.x;
+            dense_out[(c + 1) * L::D + r] = v.y;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vgpa_sym_pack(long long count, int D, const double* dense, double* packed, void* stream) {
+    VGPA_REQUIRE(count >= 0 && dense && packed, "vgpa_sym_pack: bad arguments");
+    if (D != 40) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_sym_pack: the packed layout exists for D == 40 only (got %d)", D);
+    if (count == 0) return VGPA_OK;
+    const size_t threads = (size_t)count * vgpa::SymRows40::PIECES;
+    VGPA_REQUIRE((threads + 255) / 256 < 0x7fffffffull, "vgpa_sym_pack: too many matrices for one call");
+    hipLaunchKernelGGL(sym_rows_convert_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       vgpa::as_stream(stream), (size_t)count, dense, packed);
+    return vgpa::check_launch("vgpa_sym_pack");
+}
+
+extern "C" int vgpa_sym_unpack(long long count, int D, const double* packed, double* dense, void* stream) {
+    VGPA_REQUIRE(count >= 0 && dense && packed, "vgpa_sym_unpack: bad arguments");
+    if (D != 40) return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_sym_unpack: the packed layout exists for D == 40 only (got %d)", D);
+    if (count == 0) return VGPA_OK;
+    const size_t threads = (size_t)count * vgpa::SymRows40::PIECES;
+    VGPA_REQUIRE((threads + 255) / 256 < 0x7fffffffull, "vgpa_sym_unpack: too many matrices for one call");
+    hipLaunchKernelGGL(sym_rows_convert_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       vgpa::as_stream(stream), (size_t)count, packed, dense);
+    return vgpa::check_launch("vgpa_sym_unpack");
+}
+
+extern "C" int vgpa_sym_packed_size(int D) { return D == 40 ? vgpa::SymRows40::SIZE : -1; }
 
 #ifdef VGPA_STAMPS
 extern "C" int vgpa_debug_m40_stamps(unsigned long long* out16) {

@@ -171,6 +171,122 @@ struct M40Wave {
     }
 };
 
+// One wavefront's traffic for a whole matrix in the packed symmetric layout of sym_rows.h, in
+// 16-byte pieces: nine instructions instead of thirteen.
+//   instructions 0, 1   rows  0 .. 15, eight rows each (8 pieces a row)
+//   instructions 2 .. 5 rows 16 .. 31, four rows each (16 pieces a row)
+//   instructions 6 .. 8 rows 32 .. 39, three rows each on 60 lanes (20 pieces a row, the padding
+//                       is skipped); the last one has rows 38 and 39 only: the lanes of its
+//                       third row repeat row 39, and lanes 60 .. 63 repeat lane 59 (same values
+//                       to the same addresses)
+// so that every address is one of three per-lane bases plus a compile-time offset.  With MIRROR a
+// piece left of its diagonal block is also written transposed: the LDS image is the full matrix.
+struct M40Packed {
+    static constexpr int NQ = 9, LD = M40::LD, SIZE = vgpa::SymRows40::SIZE;
+    int row[3], col[3], lr;
+    __device__ __forceinline__ explicit M40Packed(int lane) {
+        row[0] = lane >> 3;
+        col[0] = 2 * (lane & 7);
+        row[1] = 16 + (lane >> 4);
+        col[1] = 2 * (lane & 15);
+        const int l60 = min(lane, 59);
+        lr = (l60 >= 20) + (l60 >= 40);
+        row[2] = 32 + lr;
+        col[2] = 2 * (l60 - 20 * lr);
+    }
+    static __device__ __forceinline__ constexpr int group(int k) { return k < 2 ? 0 : (k < 6 ? 1 : 2); }
+    // matrix row of this lane's piece in instruction k
+    __device__ __forceinline__ int prow(int k) const {
+        if (k < 2) return row[0] + 8 * k;
+        if (k < 6) return row[1] + 4 * (k - 2);
+        return row[2] + 3 * (k - 6) - ((k == 8 && lr == 2) ? 1 : 0);
+    }
+    __device__ __forceinline__ int pcol(int k) const { return col[group(k)]; }
+    // index of the piece in global memory
+    __device__ __forceinline__ int gpiece(int k) const {
+        const int r = prow(k);
+        return (k < 2 ? 8 * r : (k < 6 ? 128 + 16 * (r - 16) : 384 + 24 * (r - 32))) + (pcol(k) >> 1);
+    }
+    __device__ __forceinline__ bool mirrored(int k) const { return k >= 2 && pcol(k) < (k < 6 ? 16 : 32); }
+
+    __device__ __forceinline__ void fetch1(const double* __restrict__ src, int k, double& x, double& y) const {
+        const double2 v = vgpa::ld_once(reinterpret_cast<const double2*>(src) + gpiece(k));
+        x = v.x;
+        y = v.y;
+    }
+    template <bool MIRROR>
+    __device__ __forceinline__ void commit1(double x, double y, int k, double* dst) const {
+        const int r = prow(k), c = pcol(k);
+        *reinterpret_cast<double2*>(dst + r * LD + c) = make_double2(x, y);
+        if (MIRROR && mirrored(k)) {
+            dst[c * LD + r] = x;
+            dst[(c + 1) * LD + r] = y;
+        }
+    }
+    __device__ __forceinline__ void fetch(const double* __restrict__ src, double (&pre)[2 * NQ]) const {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) fetch1(src, k, pre[2 * k], pre[2 * k + 1]);
+    }
+    template <bool MIRROR>
+    __device__ __forceinline__ void commit(const double (&pre)[2 * NQ], double* dst) const {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) commit1<MIRROR>(pre[2 * k], pre[2 * k + 1], k, dst);
+    }
+    // LDS matrix -> packed global matrix
+    __device__ __forceinline__ void write_out(const double* src, double* __restrict__ dst) const {
+        double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            vgpa::st_once(d2 + gpiece(k), *reinterpret_cast<const double2*>(src + prow(k) * LD + pcol(k)));
+    }
+    // A third of the matrix for wavefront r of three: instructions {0, 2, 6}, {1, 3, 7}, {4, 5, 8}.
+    static __device__ __forceinline__ constexpr int third(int r, int q) {
+        return r == 0 ? (q == 0 ? 0 : (q == 1 ? 2 : 6)) : (r == 1 ? (q == 0 ? 1 : (q == 1 ? 3 : 7)) : (q == 0 ? 4 : (q == 1 ? 5 : 8)));
+    }
+    template <int R>
+    __device__ __forceinline__ void fetch_third_r(const double* __restrict__ src, double (&pre)[6]) const {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fetch1(src, third(R, q), pre[2 * q], pre[2 * q + 1]);
+    }
+    template <int R>
+    __device__ __forceinline__ void commit_third_r(const double (&pre)[6], double* dst) const {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) commit1<true>(pre[2 * q], pre[2 * q + 1], third(R, q), dst);
+    }
+    __device__ __forceinline__ void fetch_third(const double* __restrict__ src, int r, double (&pre)[6]) const {
+        if (r == 0) fetch_third_r<0>(src, pre);
+        else if (r == 1) fetch_third_r<1>(src, pre);
+        else fetch_third_r<2>(src, pre);
+    }
+    __device__ __forceinline__ void commit_third(const double (&pre)[6], int r, double* dst) const {
+        if (r == 0) commit_third_r<0>(pre, dst);
+        else if (r == 1) commit_third_r<1>(pre, dst);
+        else commit_third_r<2>(pre, dst);
+    }
+    // Whole-workgroup copies for the first row of a scan: a packed global matrix into a full LDS image,
+    // and a dense global matrix (or zero) into a packed global one.
+    static __device__ __forceinline__ void load_image(const double* __restrict__ src, int tid, int nt, double* dst) {
+        for (int e = tid; e < SIZE; e += nt) {
+            int r, c;
+            vgpa::SymRows40::coords(e, r, c);
+            if (c < M40::D) {
+                const double v = src[e];
+                dst[r * LD + c] = v;
+                dst[c * LD + r] = v;
+            }
+        }
+    }
+    static __device__ __forceinline__ void pack_dense(const double* __restrict__ dense, int tid, int nt, double* __restrict__ dst) {
+        for (int e = tid; e < SIZE; e += nt) {
+            int r, c;
+            vgpa::SymRows40::coords(e, r, c);
+            if (c < M40::D) dst[e] = dense ? dense[r * M40::D + c] : 0.0;
+        }
+    }
+};
+
+// PACKED: S_out is written in the packed symmetric layout (sym_rows.h), 1152 doubles a row.
+template <bool PACKED>
 __global__ void __launch_bounds__(M40::NT)
 fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* __restrict__ b,
                             const double* __restrict__ m0, const double* __restrict__ S0,
@@ -190,7 +306,8 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
     const double* S0p = S0 + (size_t)p * DD;
     const double* Sgp = Sigma + (size_t)p * sigma_stride;
     double* mo = m_out + (size_t)p * N * D;
-    double* So = S_out + (size_t)p * N * DD;
+    constexpr int SS = PACKED ? M40Packed::SIZE : DD;       // doubles per stored S(t)
+    double* So = S_out + (size_t)p * N * SS;
     const int vl = min(lane, D - 1);
 
     for (int e = tid; e < DD; e += M40::NT) {
@@ -198,8 +315,9 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
         Ab[o] = Ap[e];
         const double sv = S0p[e];
         Sb[o] = sv;
-        So[e] = sv;
+        if (!PACKED) So[e] = sv;
     }
+    if (PACKED) M40Packed::pack_dense(S0p, tid, M40::NT, So);
 
     if (wid < 3) {
         // ---- matrix wavefronts: no global memory traffic inside the time loop ----------
@@ -242,7 +360,10 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
 
         auto step = [&](int t, double (&pre)[2 * M40Wave::NQ], double& bnext) __attribute__((always_inline)) {
             __syncthreads();                   // A[t], S[t], m[t], b[t] are in LDS
-            if (t > 0) M40Wave::write_out(Sb, lane, So + (size_t)t * DD);
+            if (t > 0) {
+                if (PACKED) M40Packed(lane).write_out(Sb, So + (size_t)t * SS);
+                else M40Wave::write_out(Sb, lane, So + (size_t)t * DD);
+            }
             if (lane < D) {
                 const double* row = Ab + lane * LD;
                 double d0 = 0.0, d1 = 0.0;
@@ -271,7 +392,10 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
             if (t + 2 < N) step(t + 1, preB, bB);
         }
         __syncthreads();
-        if (N > 1) M40Wave::write_out(Sb, lane, So + (size_t)(N - 1) * DD);
+        if (N > 1) {
+            if (PACKED) M40Packed(lane).write_out(Sb, So + (size_t)(N - 1) * SS);
+            else M40Wave::write_out(Sb, lane, So + (size_t)(N - 1) * DD);
+        }
     }
 }
 

@@ -261,18 +261,41 @@ def _bitwise_symmetric(t):
     return bool(torch.equal(t, t.transpose(-1, -2)))
 
 
-def fwd_scan(method, A, b, m0, S0, Sigma, dt, symmetric=None):
+def sym_pack(dense):
+    """vgpa_sym_pack: (..., 40, 40) symmetric matrices -> (..., 1152), the packed layout the
+    Lorenz-96 Euler kernels accept (see ``include/vgpa.h``)."""
+    if dense.shape[-1] != 40 or dense.shape[-2] != 40:
+        raise ValueError("sym_pack: the packed layout exists for 40 x 40 matrices only")
+    dense = dense.contiguous()
+    out = torch.empty(dense.shape[:-2] + (_lib.SYM_PACKED_40,), dtype=F64, device=dense.device)
+    call("vgpa_sym_pack", dense.numel() // 1600, 40, _p(dense), _p(out), _stream())
+    return out
+
+
+def sym_unpack(packed):
+    """vgpa_sym_unpack: (..., 1152) -> (..., 40, 40), mirrored above the block diagonal."""
+    if packed.shape[-1] != _lib.SYM_PACKED_40:
+        raise ValueError("sym_unpack: the last axis must hold %d doubles" % _lib.SYM_PACKED_40)
+    packed = packed.contiguous()
+    out = torch.empty(packed.shape[:-1] + (40, 40), dtype=F64, device=packed.device)
+    call("vgpa_sym_unpack", packed.numel() // _lib.SYM_PACKED_40, 40, _p(packed), _p(out), _stream())
+    return out
+
+
+def fwd_scan(method, A, b, m0, S0, Sigma, dt, symmetric=None, packed=False):
     """vgpa_fwd_scan.  A (P,N,D,D) / (P,N) -> m, S.  ``symmetric`` selects the
-    one-product-per-stage kernels; None checks S0 and Sigma for exact symmetry."""
+    one-product-per-stage kernels; None checks S0 and Sigma for exact symmetry.
+    ``packed``: S comes back as (P,N,1152) in the packed symmetric layout (Euler, D = 40,
+    symmetric only; anything else raises)."""
     P, N = A.shape[0], A.shape[1]
     D = 1 if A.dim() == 2 else A.shape[-1]
     vs, ms = _mat_shape(P, N, D)
     m = torch.empty(vs, dtype=F64, device=A.device)
-    S = torch.empty(ms, dtype=F64, device=A.device)
+    S = torch.empty((P, N, _lib.SYM_PACKED_40) if packed else ms, dtype=F64, device=A.device)
     sstride = _par_stride(Sigma, P, D * D)
     if symmetric is None:
         symmetric = D > 1 and _bitwise_symmetric(S0) and _bitwise_symmetric(Sigma)
-    flags = _lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0
+    flags = (_lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0) | (_lib.SCAN_PACKED if packed else 0)
     call("vgpa_fwd_scan", method, P, N, D, _p(A), _p(b), _p(m0), _p(S0), _p(Sigma), sstride, float(dt), flags,
          _p(m), _p(S), _stream())
     return m, S
@@ -297,7 +320,8 @@ def bwd_scan(method, A, dEdm, dEdS, dEobs_dm, dt, dEobs_dS=None, obs_flag=None, 
 
 
 def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, dEobs_dS=None, symmetric=False,
-                  state_symmetric=False, outer=False, lam_last=None, Psi_last=None, out=None, costate=True):
+                  state_symmetric=False, outer=False, lam_last=None, Psi_last=None, out=None, costate=True,
+                  packed=False):
     """vgpa_bwd_scan_grad -> lam, Psi, gLA, gLb: the backward scan and the gradient assembly
     in one call.  With the Euler method at D = 40, symmetric inputs (``symmetric``: dEdS and
     the jumps; ``state_symmetric``: S), an implicit Lorenz-96 <df/dx> (Edf None) and a diagonal
@@ -305,7 +329,10 @@ def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, d
 
     ``costate=False``: the caller does not need Psi(t) beyond t = 0 (an optimiser wants F and the
     gradient only).  Where the one-kernel path runs, Psi then comes back as (P, 1, D, D) holding
-    Psi(0) and the other rows are never written; elsewhere the argument changes nothing."""
+    Psi(0) and the other rows are never written; elsewhere the argument changes nothing.
+
+    ``packed``: S and dEdS are given, and Psi comes back, in the packed symmetric layout
+    ((P, N, 1152), see ``sym_pack``); only where the one-kernel Euler path runs, anything else raises."""
     P, N, D = prob.P, prob.N, prob.D
     lam = torch.empty_like(dEdm)
     sflags = (_lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0) | \
@@ -314,9 +341,11 @@ def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, d
     if not costate and _lib.lib.vgpa_bwd_scan_grad_is_fused(prob.method, P, D, sflags, gflags, int(dEobs_dS is not None),
                                                            int(Edf is not None), prob.system):
         sflags |= _lib.SCAN_PSI_ROW0
-        Psi = torch.empty((P, 1, D, D), dtype=F64, device=dEdS.device)
+        Psi = torch.empty((P, 1, _lib.SYM_PACKED_40) if packed else (P, 1, D, D), dtype=F64, device=dEdS.device)
     else:
         Psi = torch.empty_like(dEdS)
+    if packed:
+        sflags |= _lib.SCAN_PACKED
     if out is None:
         gLA, gLb = torch.empty_like(A), torch.empty_like(b)
     else:
@@ -364,6 +393,28 @@ def esde(system, A, b, m, S, sig_inv_diag, theta, want_edf=True, want_hyper=True
     return out
 
 
+def esde_l96_packed(A, b, m, S, sig_inv_diag, theta, want_hyper=True):
+    """vgpa_esde_l96_ut_packed -> the dict of ``esde`` with dEdS (P,N,1152) and no Edf; S is (P,N,1152)."""
+    P, N, D = A.shape[0], A.shape[1], A.shape[-1]
+    if D != 40 or S.shape != (P, N, _lib.SYM_PACKED_40):
+        raise ValueError("esde_l96_packed: needs D == 40 and S of shape (P, N, %d)" % _lib.SYM_PACKED_40)
+    dev = A.device
+    out = dict(
+        Esde_t=torch.empty((P, N), dtype=F64, device=dev),
+        Ef=torch.empty((P, N, D), dtype=F64, device=dev),
+        Edf=None,
+        dEdm=torch.empty((P, N, D), dtype=F64, device=dev),
+        dEdS=torch.empty_like(S),
+        dth_t=torch.empty((P, N, D), dtype=F64, device=dev) if want_hyper else None,
+        dSig_t=torch.empty((P, N, D), dtype=F64, device=dev) if want_hyper else None,
+        status=torch.zeros((P, N), dtype=torch.int32, device=dev),
+    )
+    call("vgpa_esde_l96_ut_packed", P, N, _p(A), _p(b), _p(m), _p(S), _p(sig_inv_diag), _par_stride(sig_inv_diag, P, D),
+         _p(theta), _par_stride(theta, P, 1), _p(out["Esde_t"]), _p(out["Ef"]), _p(out["dEdm"]), _p(out["dEdS"]),
+         _p(out["dth_t"]), _p(out["dSig_t"]), _p(out["status"]), _stream())
+    return out
+
+
 def reduce_energy(x, w, scale):
     """vgpa_reduce_energy: x (P,N) or (P,N,C) -> (P,) or (P,C)."""
     P, N = x.shape[0], x.shape[1]
@@ -373,8 +424,9 @@ def reduce_energy(x, w, scale):
     return out
 
 
-def obs_terms(prob, m, S):
-    """vgpa_obs_terms -> Eobs (P,), dEobs_dm (like m), jumpS (D,D)."""
+def obs_terms(prob, m, S, packed=False):
+    """vgpa_obs_terms -> Eobs (P,), dEobs_dm (like m), jumpS (D,D).  ``packed``: S is (P,N,1152)
+    in the packed symmetric layout (D = 40)."""
     P, N, D = prob.P, prob.N, prob.D
     Eobs = torch.empty((P,), dtype=F64, device=m.device)
     dm = torch.empty_like(m)
@@ -386,8 +438,14 @@ def obs_terms(prob, m, S):
     d = prob.obsY.shape[-1]
     ystride = prob.M * d if (prob.obsY.dim() == 3 and P > 1) else 0
     work = torch.empty((P, max(prob.M, 1)), dtype=F64, device=m.device)
-    call("vgpa_obs_terms", P, N, D, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
-         _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(work), _p(Eobs), _p(dm), _p(jumpS), _stream())
+    if packed:
+        if D != 40:
+            raise ValueError("obs_terms: the packed layout exists for D == 40 only")
+        call("vgpa_obs_terms_packed", P, N, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
+             _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(work), _p(Eobs), _p(dm), _p(jumpS), _stream())
+    else:
+        call("vgpa_obs_terms", P, N, D, prob.M, d, _p(m), _p(S), _p(prob.obs_idx), _p(prob.obsY), ystride,
+             _p(prob.H), _p(prob.Ri), _p(prob.Qi), prob.logconst, _p(work), _p(Eobs), _p(dm), _p(jumpS), _stream())
     if fresh:
         prob.jumps_cache = (key, jumpS)
     return Eobs, dm, prob.jumps_cache[1]
@@ -491,13 +549,18 @@ def hyper_gradients(system, D, SigInv, sig_inv_diag, Esde, tr_th, tr_sig):
     return sig_inv_diag * tr_th, -0.5 * SigInv @ torch.diag_embed(tr_sig) @ SigInv
 
 
-def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hyper=True, want_edf=True):
+def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hyper=True, want_edf=True, packed=False):
     """The ``energy_mode`` contract on device: per-step kernel + time reductions.
     Returns a dict with Esde (P,), Ef, Edf, dEdm, dEdS, dth, dSig, status; with
     ``want_hyper`` also the raw time integrals tr_th, tr_sig the hyper-gradients are
     formed from (what time windows add up)."""
     D = 1 if A.dim() == 2 else A.shape[-1]
-    out = esde(system, A, b, m, S, sig_inv_diag, theta, want_edf, want_hyper)
+    if packed:
+        if system != _lib.SYS_L96_UT or want_edf:
+            raise ValueError("energy_terms: packed matrices need the Lorenz-96 system and want_edf=False")
+        out = esde_l96_packed(A, b, m, S, sig_inv_diag, theta, want_hyper)
+    else:
+        out = esde(system, A, b, m, S, sig_inv_diag, theta, want_edf, want_hyper)
     out["Esde"] = reduce_energy(out["Esde_t"], w, dt)
     if want_hyper:
         out["tr_th"] = reduce_energy(out["dth_t"], w, dt)
@@ -590,24 +653,44 @@ def gradient(prob, A, b, st, outer=False, out=None):
     return grad_assemble(prob, A, b, st.m, st.S, st.lam, st.Psi, st.Ef, st.Edf, outer=outer, out=out)
 
 
-def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer=False, out=None, costate=True):
+def packed_supported(prob, outer=False):
+    """Whether ``free_energy_and_gradient(..., packed=True)`` can run for this problem: the Lorenz-96
+    D = 40 Euler case where the backward scan and the gradient are one kernel."""
+    if prob.system != _lib.SYS_L96_UT or prob.D != 40 or prob.method != _lib.EULER or not (prob.sym_fwd and prob.sym_jump):
+        return False
+    sflags = _lib.SCAN_SYMMETRIC | _lib.SCAN_STATE_SYMMETRIC
+    gflags = (_lib.GRAD_OUTER if outer else 0) | (_lib.GRAD_SIGINV_DIAG if prob.sig_is_diag else 0)
+    return bool(_lib.lib.vgpa_bwd_scan_grad_is_fused(prob.method, prob.P, prob.D, sflags, gflags, 0, 0, prob.system))
+
+
+def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer=False, out=None, costate=True,
+                             packed=False):
     """core/varFreeEnergy.py:80-111 followed by core/gradL_Ab.py:156-180 for a batch, with the
     backward scan and the gradient assembly in one library call (one kernel for the Lorenz-96
     D = 40 Euler case, see ``bwd_scan_grad``).  Returns (State, gLA, gLb).  ``costate=False``: State.Psi
-    may hold row 0 only (see ``bwd_scan_grad``); for callers that use F and the gradient alone."""
+    may hold row 0 only (see ``bwd_scan_grad``); for callers that use F and the gradient alone.
+
+    ``packed=True`` (only where ``packed_supported(prob)``): the symmetric matrices of every time row
+    -- State.S, State.dEdS, State.Psi -- are kept as (P, N, 1152) in the packed layout of ``sym_pack``
+    instead of (P, N, 40, 40); ``sym_unpack`` expands them.  F, the gradient and every vector are the
+    same as without it (the energy kernel bit for bit, the scans to rounding: same products, same
+    order); the evaluation moves 16 % fewer bytes.  State.Edf is None."""
+    if packed and (prob.system < 0 or want_edf or not packed_supported(prob, outer)):
+        raise ValueError("free_energy_and_gradient: packed=True needs the Lorenz-96 D = 40 Euler problem with diagonal "
+                         "noise, more than 160 problems, and want_edf=False (see packed_supported)")
     if prob.system < 0:
         st = free_energy(prob, A, b, want_hyper=want_hyper, want_edf=True)
         gLA, gLb = gradient(prob, A, b, st, outer=outer, out=out)
         return st, gLA, gLb
-    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd)
-    Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S)
+    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd, packed=packed)
+    Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S, packed=packed)
     implicit_ok = prob.D > 1 and prob.system in (_lib.SYS_L96_UT, _lib.SYS_L63, _lib.SYS_L63_UT)
     en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w, prob.dt,
-                      want_hyper, want_edf=want_edf or not implicit_ok)
+                      want_hyper, want_edf=want_edf or not implicit_ok, packed=packed)
     sym = prob.sym_jump and esde_output_is_symmetric(prob.system, prob.D)
     lam, Psi, gLA, gLb = bwd_scan_grad(prob, A, b, m, S, en["dEdm"], en["dEdS"], dEobs_dm, en["Ef"], en["Edf"],
                                        jumpS=jumpS, symmetric=sym, state_symmetric=prob.sym_fwd, outer=outer, out=out,
-                                       costate=costate)
+                                       costate=costate, packed=packed)
     KL0 = kl0(prob)
     F = KL0 + Eobs + en["Esde"]
     st = State(F=F, KL0=KL0, Eobs=Eobs, Esde=en["Esde"], m=m, S=S, lam=lam, Psi=Psi, Ef=en["Ef"], Edf=en["Edf"],
