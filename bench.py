@@ -37,9 +37,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64, vector and matrix alike
-ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false>"
-KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel", "esde": ESDE_KERNEL,
-                "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel"}
+ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false, false>"
+KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel<false>", "esde": ESDE_KERNEL,
+                "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel<false>"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
 STREAM_FILE = os.path.join(ROOT, "profiles", "r3_hbm_stream_probe.txt")
 REFERENCE_FILE = os.path.join(ROOT, "profiles", "r3_time_reference.txt")

@@ -19,7 +19,7 @@ def short(name):
 rows = list(csv.DictReader(open(os.path.join(PF, "kernel_stats.csv"))))
 with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-parity   "
-            "(1 MI355X, 512 problems, N=2002, 7 evaluations)\n")
+            "(1 MI355X, 512 problems, N=2002; 7 evaluations of the timed path = kernels <false>, 6 of the optimiser path = kernels <true>)\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in rows:
         f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
@@ -44,7 +44,12 @@ def counters(sub):
 # 2. HBM traffic
 fe, wr = counters("fetch"), counters("write")
 units = 512 * 2002
-alg = {"fwd_euler_sym_mfma40_kernel": 26240, "esde_l96_ut_wave40_kernel<false>": 39688, "bwd_grad_euler_sym_mfma40_kernel": 66240}
+alg = {"fwd_euler_sym_mfma40_kernel<false>": 26240, "esde_l96_ut_wave40_kernel<false, false>": 39688,
+       "bwd_grad_euler_sym_mfma40_kernel<false>": 66240,
+       # the optimiser path of bench.py: packed symmetric matrices (1088 kept entries in rows of 1152 doubles),
+       # Psi(t) stored for t = 0 only
+       "fwd_euler_sym_mfma40_kernel<true>": 8 * (1600 + 1088 + 80), "esde_l96_ut_wave40_kernel<false, true>": 8 * (1600 + 2 * 1088 + 161),
+       "bwd_grad_euler_sym_mfma40_kernel<true>": 8 * (2 * 1600 + 2 * 1088 + 280)}
 text = [f"# HBM traffic per launch from rocprofv3 PMC counters ({tag})",
         "# commands (two separate passes): rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity   (512 problems, the size bench.py times)",
         "#                                 rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity   (512 problems, the size bench.py times)",
@@ -54,6 +59,8 @@ text = [f"# HBM traffic per launch from rocprofv3 PMC counters ({tag})",
         "# bench.py reads the LAST line below whose first field is the kernel it reports the roofline for.",
         "kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,read_bytes(2x),write_bytes,total_bytes,bytes_per_unit,algorithmic_bytes_per_unit"]
 for k, a in alg.items():
+    if k not in fe or k not in wr:
+        continue
     f_, w_ = fe[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"]
     rb, wb = 2 * 1024 * f_, 1024 * w_
     text.append(f"{k},{f_:.0f},{w_:.0f},{rb:.4g},{wb:.4g},{rb + wb:.4g},{(rb + wb) / units:.0f},{a}")
@@ -61,7 +68,7 @@ for name in (f"{tag}_pmc_hbm_traffic.txt", "pmc_hbm_traffic.txt"):
     open(os.path.join(ROOT, "profiles", name), "w").write("\n".join(text) + "\n")
 
 # 3. issue / busy counters of the energy kernel
-k = "esde_l96_ut_wave40_kernel<false>"
+k = "esde_l96_ut_wave40_kernel<false, false>"
 sq = dict(counters("sq_a")[k]); sq.update(counters("sq_b")[k])
 steps = units
 lines = [f"# rocprofv3 --pmc <counters> -- python3 tools/diag/esde_only.py 512   ({tag}; two passes; averages over 3 launches of {k},",
