@@ -193,3 +193,35 @@ def test_packed_layout_is_refused_where_no_kernel_takes_it():
     euler, A, b = _l96_problem(4, FUSED_P, 11)
     with pytest.raises(_lib.VgpaError, match="VGPA_SCAN_PACKED"):
         engine.fwd_scan(euler.method, A, b, euler.m0, euler.S0, euler.Sigma, euler.dt, symmetric=False, packed=True)
+
+
+def test_batched_optimiser_takes_the_packed_path_and_follows_the_dense_trajectory():
+    """scg_batched keeps the symmetric intermediates packed where the kernels take them; its iterates
+    are those of a run whose evaluations go through the dense kernels (auxiliary/optimize.py:132-238)."""
+    import torch
+    from vgpa_amd import engine
+    from vgpa_amd.auxiliary.optimize import scg_batched
+    N = 12
+    prob, A, b = _l96_problem(N, FUSED_P, 41)
+    assert engine.packed_supported(prob)
+    calls = []
+    real = engine.free_energy_and_gradient
+
+    def spy(*a, **kw):
+        calls.append(bool(kw.get("packed")))
+        return real(*a, **kw)
+
+    engine.free_energy_and_gradient = spy
+    try:
+        A1, b1, F1, stat1 = scg_batched(prob, A, b, nit=4)
+    finally:
+        engine.free_energy_and_gradient = real
+    assert calls and all(calls)
+
+    def dense(Ax, bx, need_grad):
+        st, gA, gb = real(prob, Ax, bx)
+        return st.F, torch.cat((gA.reshape(FUSED_P, -1), gb.reshape(FUSED_P, -1)), dim=1)
+
+    A2, b2, F2, stat2 = scg_batched(prob, A, b, nit=4, evaluate=dense)
+    assert torch.equal(F1, F2) and torch.equal(A1, A2) and torch.equal(b1, b2)
+    assert torch.equal(stat1["Fx"], stat2["Fx"])

@@ -420,11 +420,15 @@ def scg_batched(prob, A0, b0, nit=150, xtol=1.0e-6, ftol=1.0e-8, evaluate=None, 
     P, n, nA = ops.P, ops.n, ops.nA
     dev, f64, i32 = ops.dev, torch.float64, torch.int32
 
+    # F and the gradient are all the recursion uses: the symmetric intermediates stay in their packed
+    # form where the kernels take it (same bits, fewer bytes) and the rows of Psi are not stored
+    packed = evaluate is None and engine.packed_supported(prob)
+
     def fg(v, g_out):
         """F at the parameter array v; the gradient goes into g_out."""
         A, b = ops.parts(v)
         if evaluate is None:
-            st, _, _ = engine.free_energy_and_gradient(prob, A, b, out=ops.parts(g_out), costate=False)
+            st, _, _ = engine.free_energy_and_gradient(prob, A, b, out=ops.parts(g_out), costate=False, packed=packed)
             return st.F
         F, grad = evaluate(A, b, True)
         gA, gb = ops.rows(g_out)
