@@ -545,7 +545,7 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
             if (c < D) {
                 const double v = Sg[q];
                 Sm[r * LD + c] = v;
-                Sm[c * LD + r] = v;
+                if (c < 16 * (r / 16)) Sm[c * LD + r] = v;       // left of the diagonal block: the mirror image too
             }
         }
     }

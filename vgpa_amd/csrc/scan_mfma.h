@@ -27,7 +27,10 @@ __device__ unsigned long long g_m40_stamps[128];
 #define M40_STAMP(k) do { if (blockIdx.x == 7 && t == 1000 && lane == 0) g_m40_stamps[wid * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 // fused kernel: eight wavefronts, stamps of steps t = 1000 (slots 0..7) and t = 999 (slots 8..15)
 #define M40F_STAMP(k) do { if (blockIdx.x == 7 && (t == 1000 || t == 999) && lane == 0) g_m40_stamps[wid * 16 + (t == 999 ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// forward scan: four wavefronts, stamps of steps t = 1000 (slots 0..7) and t = 1001 (slots 8..15)
+#define M40W_STAMP(k) do { if (blockIdx.x == 7 && (t == 1000 || t == 1001) && lane == 0) g_m40_stamps[wid * 16 + (t == 1001 ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define M40W_STAMP(k) do { } while (0)
 #define M40_STAMP(k) do { } while (0)
 #define M40F_STAMP(k) do { } while (0)
 #endif
@@ -272,7 +275,7 @@ struct M40Packed {
             if (c < M40::D) {
                 const double v = src[e];
                 dst[r * LD + c] = v;
-                dst[c * LD + r] = v;
+                if (c < 16 * (r / 16)) dst[c * LD + r] = v;      // left of the diagonal block: the mirror image too
             }
         }
     }
@@ -330,10 +333,14 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
 #pragma unroll 1
         for (int t = 0; t + 1 < N; ++t) {
             __syncthreads();                   // A[t], S[t] are in LDS
+            M40W_STAMP(0);
             mfma_f64x4 acc[3];
             m40_rows_x_rows(Ab, Sb, wid, lane, acc);
+            M40W_STAMP(4);
             M40_FOR(c, reg) Mt[L.l[c][reg]] = acc[c][reg];
+            M40W_STAMP(1);
             __syncthreads();                   // A S complete; A[t], S[t] no longer read
+            M40W_STAMP(2);
             M40_FOR(c, reg) {
                 const double mt = Mt[L.lt[c][reg]];
                 const double k1 = -acc[c][reg] - mt + sig[c][reg];   // core/fwd_ode.py:45
@@ -341,6 +348,7 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
                 s[c][reg] = sn;
                 Sb[L.l[c][reg]] = sn;
             }
+            M40W_STAMP(3);
         }
         __syncthreads();
     } else {
@@ -360,6 +368,7 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
 
         auto step = [&](int t, double (&pre)[2 * M40Wave::NQ], double& bnext) __attribute__((always_inline)) {
             __syncthreads();                   // A[t], S[t], m[t], b[t] are in LDS
+            M40W_STAMP(0);
             if (t > 0) {
                 if (PACKED) M40Packed(lane).write_out(Sb, So + (size_t)t * SS);
                 else M40Wave::write_out(Sb, lane, So + (size_t)t * DD);
@@ -377,15 +386,19 @@ fwd_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* _
                 mreg = mreg + f1 * dt;
                 mo[(size_t)(t + 1) * D + lane] = mreg;
             }
+            M40W_STAMP(1);
             __syncthreads();                   // A[t], S[t], m[t] no longer read
+            M40W_STAMP(2);
             if (lane < D) {
                 mvv[lane] = mreg;
                 bv[lane] = bnext;
             }
             M40Wave::commit<false>(pre, lane, Ab);
+            M40W_STAMP(4);
             const int tp = (t + 3 < N) ? t + 3 : N - 1;
             M40Wave::fetch(Ap + (size_t)tp * DD, lane, pre);
             bnext = bp[(size_t)tp * D + vl];
+            M40W_STAMP(3);
         };
         for (int t = 0; t + 1 < N; t += 2) {
             step(t, preA, bA);
