@@ -245,7 +245,7 @@ def launch_ranks(args, argv):
                 continue
             except ValueError:
                 pass
-        sys.stdout.write(ln)       # anything else the ranks print is passed on
+        sys.stderr.write(ln)       # anything else the ranks print goes to stderr: stdout carries the one JSON line
     rc = proc.wait()
     if line is not None:
         if cpu is not None:

@@ -44,8 +44,10 @@ def test_launcher_passes_arguments_through(monkeypatch, capsys):
     k = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[k + 1:k + 1 + len(argv)] == argv          # every argument, in order
     assert cmd[-1] == "--no-cpu"                        # the ranks do not repeat the CPU baseline
-    out = capsys.readouterr().out.strip().splitlines()
-    assert out[0] == "some rank chatter"
+    captured = capsys.readouterr()
+    out = captured.out.strip().splitlines()
+    assert len(out) == 1                                # stdout carries the JSON line alone
+    assert "some rank chatter" in captured.err          # what else the ranks print goes to stderr
     line = json.loads(out[-1])
     assert line["n_gpus"] == 2 and line["cpu_baseline"]["value"] == 2.0 and "launcher" in line
 
