@@ -191,3 +191,27 @@ def test_fused_evaluation_without_costate_rows(N, method):
                   p_(en["dEdS"]), p_(st3.dEobs_dm), None, p_(small.obs_flag), p_(st3.jumpS), 0, p_(st3.Ef), None,
                   small.system, p_(small.theta), 1, p_(small.SigInv), 0, float(small.dt), sf | _lib.SCAN_PSI_ROW0,
                   _lib.GRAD_SIGINV_DIAG, None, None, p_(lam), p_(Psi), p_(gA), p_(gb), None)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_parameter_arrays_aligned_to_eight_bytes_only(packed):
+    """The D = 40 kernels move 16-byte pieces; a view that starts on an odd double (8-byte aligned, as any
+    slice of a float64 buffer may be) must give the same bits, for inputs and for the gradient outputs."""
+    import torch
+    from vgpa_amd import engine
+    prob, A, b = _l96_problem(33, FUSED_P, 5)
+
+    def shifted(t):
+        flat = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        view = flat[1:].view(t.shape)
+        view.copy_(t)
+        return view
+
+    A2, b2 = shifted(A), shifted(b)
+    assert A2.data_ptr() % 16 == 8 and b2.data_ptr() % 16 == 8
+    st, gA, gb = engine.free_energy_and_gradient(prob, A, b, packed=packed)
+    out = (shifted(torch.empty_like(A)), shifted(torch.empty_like(b)))
+    st2, gA2, gb2 = engine.free_energy_and_gradient(prob, A2, b2, out=out, packed=packed)
+    assert gA2.data_ptr() == out[0].data_ptr()
+    assert torch.equal(st.F, st2.F) and torch.equal(st.Psi, st2.Psi) and torch.equal(st.S, st2.S)
+    assert torch.equal(gA, gA2) and torch.equal(gb, gb2)
