@@ -213,5 +213,6 @@ def test_parameter_arrays_aligned_to_eight_bytes_only(packed):
     out = (shifted(torch.empty_like(A)), shifted(torch.empty_like(b)))
     st2, gA2, gb2 = engine.free_energy_and_gradient(prob, A2, b2, out=out, packed=packed)
     assert gA2.data_ptr() == out[0].data_ptr()
-    assert torch.equal(st.F, st2.F) and torch.equal(st.Psi, st2.Psi) and torch.equal(st.S, st2.S)
+    full = engine.sym_unpack if packed else (lambda x: x)     # the padding of a packed row is never written
+    assert torch.equal(st.F, st2.F) and torch.equal(full(st.Psi), full(st2.Psi)) and torch.equal(full(st.S), full(st2.S))
     assert torch.equal(gA, gA2) and torch.equal(gb, gb2)
