@@ -131,6 +131,9 @@ def draw_long(rng):
                 S0=spd(rng, D, 0.2, 0.3, rng.random() < 0.5), A=A, b=b, thetas=thetas)
 
 
+PACKED_SEEN = [0]       # configurations that also ran on packed symmetric matrices
+
+
 def check(cfg, rng):
     system, D, P, N, sde = cfg["system"], cfg["D"], cfg["P"], cfg["N"], cfg["sde"]
     prob = engine.make_problem(SYS[system], sde, cfg["m0"], cfg["S0"], P=P, theta=cfg["thetas"])
@@ -168,6 +171,15 @@ def check(cfg, rng):
                 v = np.inf
             if v > worst:
                 worst, where = v, f"{k}[p={p}]"
+    if engine.packed_supported(prob):
+        # the packed symmetric layout of the Lorenz-96 Euler kernels: the same bits as the dense arrays
+        sp, pA, pb = engine.free_energy_and_gradient(prob, Ad, bd, want_hyper=True, packed=True)
+        same = (torch.equal(pA, gLA) and torch.equal(pb, gLb) and torch.equal(sp.F, st.F) and torch.equal(sp.lam, st.lam)
+                and torch.equal(engine.sym_unpack(sp.S), st.S) and torch.equal(engine.sym_unpack(sp.dEdS), st.dEdS)
+                and torch.equal(engine.sym_unpack(sp.Psi), st.Psi) and torch.equal(sp.dSig, st.dSig))
+        PACKED_SEEN[0] += 1
+        if not same:
+            worst, where = np.inf, "packed != dense"
     if P == 1:
         # the reference-signature entry points on host arrays (column or flat Ab, chosen at random)
         from vgpa_amd.core.varFreeEnergy import varFreeEnergy
@@ -287,15 +299,16 @@ def main():
     if len(sys.argv) > 3 and sys.argv[3] == "long":
         n, skipped, failures, worst_all = sweep(seed, seconds=budget, long_axes=True)
         print(f"{n} long-axis configurations, {skipped} skipped, {len(failures)} failed, worst error {worst_all:.2e} "
-              f"(tolerance {TOL:g})", flush=True)
+              f"(tolerance {TOL:g}); {PACKED_SEEN[0]} of them also on packed symmetric matrices (bitwise equal or failed)",
+              flush=True)
         sys.exit(1 if failures else 0)
     e_fail, e_worst = sweep_energy(seed, 200)
     print(f"200 energy_mode configurations with non-positive-definite steps, {len(e_fail)} failed, worst error {e_worst:.2e}",
           flush=True)
     n, skipped, failures, worst_all = sweep(seed, seconds=budget)
     failures += e_fail
-    print(f"{n} configurations, {skipped} skipped, {len(failures)} failed, worst error {worst_all:.2e} (tolerance {TOL:g})",
-          flush=True)
+    print(f"{n} configurations, {skipped} skipped, {len(failures)} failed, worst error {worst_all:.2e} (tolerance {TOL:g}); "
+          f"{PACKED_SEEN[0]} of them also on packed symmetric matrices (bitwise equal or failed)", flush=True)
     sys.exit(1 if failures else 0)
 
 
