@@ -105,7 +105,7 @@ const char* vgpa_last_error_string(void);
  * dt, method)` and its eight integrators (euler_nD :87, euler_1D :135, heun_nD
  * :181, heun_1D :247, rk2_nD :311, rk2_1D :367, rk4_nD :426, rk4_1D :493).
  *   A (P,N,D,D)  b (P,N,D)  m0 (P,D)  S0 (P,D,D)  Sigma (D,D) [sigma_stride]
- *   flags: VGPA_SCAN_SYMMETRIC or 0.
+ *   flags: VGPA_SCAN_SYMMETRIC or 0; with VGPA_SCAN_PACKED as well (Euler, D = 40) S_out is (P,N,1152).
  *   -> m_out (P,N,D), S_out (P,N,D,D);  row 0 holds (m0, S0).
  */
 int vgpa_fwd_scan(int method, int P, int N, int D,
@@ -147,6 +147,7 @@ int vgpa_bwd_scan(int method, int P, int N, int D,
  * call is bound by memory traffic); every other configuration runs the two kernels one after the
  * other.
  *   -> lam_out (P,N,D), Psi_out (P,N,D,D) [(P,1,D,D) with VGPA_SCAN_PSI_ROW0], gLA (P,N,D,D), gLb (P,N,D).
+ *   With VGPA_SCAN_PACKED: S, dEsde_dS (P,N,1152) in, Psi_out (P,N,1152) [(P,1,1152)] out.
  */
 int vgpa_bwd_scan_grad(int method, int P, int N, int D,
                        const double* A, const double* b, const double* m, const double* S,
