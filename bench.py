@@ -37,9 +37,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64, vector and matrix alike
-ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false, false>"
+ESDE_KERNEL = "esde_l96_ut_wave40_kernel<false, false, false>"
 KERNEL_NAMES = {"fwd_scan": "fwd_euler_sym_mfma40_kernel<false>", "esde": ESDE_KERNEL,
-                "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel<false>"}
+                "bwd_scan_grad": "bwd_grad_euler_sym_mfma40_kernel<false, false, false>"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.txt")
 STREAM_FILE = os.path.join(ROOT, "profiles", "r3_hbm_stream_probe.txt")
 REFERENCE_FILE = os.path.join(ROOT, "profiles", "r3_time_reference.txt")
@@ -264,6 +264,9 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("problems", "windows"), default="problems")
+    ap.add_argument("--packed-intermediate", action="store_true",
+                    help="pass dEsde/dS, the array between the energy kernel and the backward scan (not one the reference "
+                         "publishes), through memory in the packed symmetric layout; every published array stays dense")
     ap.add_argument("--no-optimiser-path", action="store_true",
                     help="skip the extra timing of the packed, gradient-only evaluation reported as `optimiser_path`")
     ap.add_argument("--problems", type=int, default=512,
@@ -344,18 +347,26 @@ def main(argv=None):
         prob = engine.make_problem(_lib.SYS_L96_UT, sde, m0, S0, P=hi - lo, theta=thetas)
         sym_bwd = prob.sym_jump and engine.esde_output_is_symmetric(prob.system, D)
         units_per_launch = (hi - lo) * N
+        packed_mid = engine.packed_supported(prob) and args.packed_intermediate
 
         def evaluate_block(timed):
             m, S = timed_call("fwd_scan", timed, lambda: engine.fwd_scan(
                 prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd))
             Eobs, dEobs_dm, jumpS = engine.obs_terms(prob, m, S)
-            en = timed_call("esde", timed, lambda: engine.esde(
-                prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
+            # dEsde/dS, an intermediate between the two kernels that the reference does not publish, goes through
+            # memory in the packed symmetric layout where the kernels take it; m, S, lam, Psi and the gradient
+            # are the dense arrays of the contract
+            if packed_mid:
+                en = timed_call("esde", timed, lambda: engine.esde_l96_packed(
+                    A, b, m, S, prob.sig_inv_diag, prob.theta, want_hyper=False, packed_S=False))
+            else:
+                en = timed_call("esde", timed, lambda: engine.esde(
+                    prob.system, A, b, m, S, prob.sig_inv_diag, prob.theta, False, False))
             Esde = engine.reduce_energy(en["Esde_t"], prob.w, prob.dt)
             # backward scan and gradient assembly: one kernel for this configuration
             lam, Psi, gLA, gLb = timed_call("bwd_scan_grad", timed, lambda: engine.bwd_scan_grad(
                 prob, A, b, m, S, en["dEdm"], en["dEdS"], dEobs_dm, en["Ef"], en["Edf"], jumpS=jumpS,
-                symmetric=sym_bwd, state_symmetric=prob.sym_fwd))
+                symmetric=sym_bwd, state_symmetric=prob.sym_fwd, packed="dEdS" if packed_mid else False))
             F = engine.kl0(prob) + Eobs + Esde
             return F, (gLA, gLb, en["status"])
 
@@ -468,6 +479,13 @@ def main(argv=None):
             # vectors (dEsde_dm, jumps, m, <f>, b) and writes Psi, dL/dA, lam, dL/db.
             per_unit = {"fwd_scan": 8 * (2 * D * D + 2 * D), "esde": bytes_per_unit,
                         "bwd_scan_grad": 8 * (5 * D * D + 7 * D)}
+            names = dict(KERNEL_NAMES)
+            if packed_mid:
+                # --packed-intermediate: dEsde/dS moves as the 1088 kept entries of a packed row instead of D^2
+                per_unit["esde"] -= 8 * (D * D - 1088)
+                per_unit["bwd_scan_grad"] -= 8 * (D * D - 1088)
+                names["esde"] = "esde_l96_ut_wave40_kernel<false, false, true>"
+                names["bwd_scan_grad"] = "bwd_grad_euler_sym_mfma40_kernel<false, true, false>"
             kernels = {k: {"avg_ms": kernel_ms[k], "bytes_per_unit": per_unit[k],
                            "achieved_GBps": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9,
                            "frac": units_per_launch * per_unit[k] / (kernel_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -475,9 +493,9 @@ def main(argv=None):
             def roof(k):
                 """The roofline object of kernel k: algorithmic bytes per launch over its measured
                 average duration, and the HBM traffic the counters of the tracked profile give."""
-                t = measured_traffic_per_unit(KERNEL_NAMES[k])
+                t = measured_traffic_per_unit(names[k])
                 sr = stream_rate(STREAM_MIX[k])
-                return {"kernel": KERNEL_NAMES[k], "bound": "hbm", "achieved": kernels[k]["achieved_GBps"],
+                return {"kernel": names[k], "bound": "hbm", "achieved": kernels[k]["achieved_GBps"],
                         "stream_same_mix": None if sr is None else
                         {"mix": STREAM_MIX[k], "GBps": sr, "frac_of_it": kernels[k]["achieved_GBps"] / sr,
                          "source": os.path.relpath(STREAM_FILE, ROOT)},

@@ -94,6 +94,17 @@ extern "C" {
                                     S0, Sigma, the jumps and the terminal state stay dense.
                                     Anything else: VGPA_EUNSUPPORTED.                          */
 
+#define VGPA_SCAN_PACKED_DEDS 16 /* vgpa_bwd_scan_grad only, same conditions: dEsde_dS alone is packed
+                                    (P,N,1152), as vgpa_esde_l96_ut_packed writes it with layout
+                                    VGPA_PACKED_DEDS; S and Psi_out stay dense.  dEsde_dS is an
+                                    intermediate of the evaluation, not one of the arrays the
+                                    reference publishes: this is the layout to use between the two
+                                    kernels when every published array is wanted dense.          */
+
+/* layout bits of vgpa_esde_l96_ut_packed */
+#define VGPA_PACKED_S    1       /* S is (P,N,1152)        */
+#define VGPA_PACKED_DEDS 2       /* dEsde_dS is (P,N,1152) */
+
 /* largest state dimension the n-D kernels accept */
 #define VGPA_MAX_D 60
 
@@ -260,15 +271,16 @@ int vgpa_sym_unpack(long long count, int D, const double* packed, double* dense,
 int vgpa_sym_packed_size(int D);
 
 /*
- * vgpa_esde_l96_ut (dynamics/sys_lorenz_96_ut.py:131) at D = 40 on packed symmetric matrices:
- * S_packed (P,N,1152) in, dEsde_dS_packed (P,N,1152) out, no Edf; the other arguments and results
- * as vgpa_esde_l96_ut.  Results are those of the dense call bit for bit when S is bitwise symmetric.
+ * vgpa_esde_l96_ut (dynamics/sys_lorenz_96_ut.py:131) at D = 40 with packed symmetric matrices:
+ * `layout` is VGPA_PACKED_S (S is (P,N,1152)), VGPA_PACKED_DEDS (dEsde_dS is (P,N,1152)), both or 0;
+ * no Edf; the other arguments and results as vgpa_esde_l96_ut.  Results are those of the dense
+ * call bit for bit when S is bitwise symmetric.
  */
-int vgpa_esde_l96_ut_packed(int P, int N,
-                            const double* A, const double* b, const double* m, const double* S_packed,
+int vgpa_esde_l96_ut_packed(int P, int N, int layout,
+                            const double* A, const double* b, const double* m, const double* S,
                             const double* sig_inv_diag, int sig_stride,
                             const double* theta, int theta_stride,
-                            double* Esde_t, double* Ef, double* dEsde_dm, double* dEsde_dS_packed,
+                            double* Esde_t, double* Ef, double* dEsde_dm, double* dEsde_dS,
                             double* dth_t, double* dSig_t, int* status, void* stream);
 
 /*

@@ -77,6 +77,12 @@ def test_packed_evaluation_equals_dense(N):
     assert torch.equal(sp.F, st.F)
     assert torch.equal(sp.lam, st.lam) and torch.equal(engine.sym_unpack(sp.Psi), st.Psi)
     assert torch.equal(pA, gLA) and torch.equal(pb, gLb)
+    # dEsde/dS alone packed: the intermediate between the energy kernel and the backward scan; S, Psi dense
+    sm, mA, mb = engine.free_energy_and_gradient(prob, A, b, want_hyper=True, packed="dEdS")
+    assert sm.S.shape == st.S.shape and sm.Psi.shape == st.Psi.shape and sm.dEdS.shape == (FUSED_P, N, SIZE)
+    assert torch.equal(sm.S, st.S) and torch.equal(sm.Psi, st.Psi) and torch.equal(sm.lam, st.lam) and torch.equal(sm.F, st.F)
+    assert torch.equal(engine.sym_unpack(sm.dEdS), st.dEdS) and torch.equal(sm.dSig, st.dSig)
+    assert torch.equal(mA, gLA) and torch.equal(mb, gLb)
     # without the costate rows
     s0, qA, qb = engine.free_energy_and_gradient(prob, A, b, packed=True, costate=False)
     assert s0.Psi.shape == (FUSED_P, 1, SIZE)
@@ -161,6 +167,9 @@ def test_packed_energy_kernel_cholesky_fallback_vs_golden():
     args = (d(A[None]), d(b[None]), d(g["m"][None]))
     dense = engine.esde(_lib.SYS_L96_UT, *args, d(S[None]), sig_inv, theta, want_edf=False)
     packed = engine.esde_l96_packed(*args, engine.sym_pack(d(S[None])), sig_inv, theta)
+    mixed = engine.esde_l96_packed(*args, d(S[None]), sig_inv, theta, packed_S=False)      # dense S in, packed dEdS out
+    assert torch.equal(mixed["status"], packed["status"]) and torch.equal(mixed["Esde_t"], packed["Esde_t"])
+    assert torch.equal(engine.sym_unpack(mixed["dEdS"]), engine.sym_unpack(packed["dEdS"]))
     assert int((packed["status"] & _lib.ST_CHOL_FALLBACK).sum().item()) >= N // 3 - 1
     assert torch.equal(packed["status"], dense["status"])
     for k in ("Esde_t", "Ef", "dEdm", "dth_t", "dSig_t"):

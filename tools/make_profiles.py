@@ -44,12 +44,12 @@ def counters(sub):
 # 2. HBM traffic
 fe, wr = counters("fetch"), counters("write")
 units = 512 * 2002
-alg = {"fwd_euler_sym_mfma40_kernel<false>": 26240, "esde_l96_ut_wave40_kernel<false, false>": 39688,
-       "bwd_grad_euler_sym_mfma40_kernel<false>": 66240,
+alg = {"fwd_euler_sym_mfma40_kernel<false>": 26240, "esde_l96_ut_wave40_kernel<false, false, false>": 39688,
+       "bwd_grad_euler_sym_mfma40_kernel<false, false, false>": 66240,
        # the optimiser path of bench.py: packed symmetric matrices (1088 kept entries in rows of 1152 doubles),
        # Psi(t) stored for t = 0 only
-       "fwd_euler_sym_mfma40_kernel<true>": 8 * (1600 + 1088 + 80), "esde_l96_ut_wave40_kernel<false, true>": 8 * (1600 + 2 * 1088 + 161),
-       "bwd_grad_euler_sym_mfma40_kernel<true>": 8 * (2 * 1600 + 2 * 1088 + 280)}
+       "fwd_euler_sym_mfma40_kernel<true>": 8 * (1600 + 1088 + 80), "esde_l96_ut_wave40_kernel<false, true, true>": 8 * (1600 + 2 * 1088 + 161),
+       "bwd_grad_euler_sym_mfma40_kernel<true, true, true>": 8 * (2 * 1600 + 2 * 1088 + 280)}
 text = [f"# HBM traffic per launch from rocprofv3 PMC counters ({tag})",
         "# commands (two separate passes): rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity   (512 problems, the size bench.py times)",
         "#                                 rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-parity   (512 problems, the size bench.py times)",
@@ -68,7 +68,7 @@ for name in (f"{tag}_pmc_hbm_traffic.txt", "pmc_hbm_traffic.txt"):
     open(os.path.join(ROOT, "profiles", name), "w").write("\n".join(text) + "\n")
 
 # 3. issue / busy counters of the energy kernel
-k = "esde_l96_ut_wave40_kernel<false, false>"
+k = "esde_l96_ut_wave40_kernel<false, false, false>"
 sq = dict(counters("sq_a")[k]); sq.update(counters("sq_b")[k])
 steps = units
 lines = [f"# rocprofv3 --pmc <counters> -- python3 tools/diag/esde_only.py 512   ({tag}; two passes; averages over 3 launches of {k},",

@@ -30,6 +30,8 @@ SCAN_SYMMETRIC = 1
 SCAN_STATE_SYMMETRIC = 2
 SCAN_PSI_ROW0 = 4
 SCAN_PACKED = 8
+SCAN_PACKED_DEDS = 16
+PACKED_S, PACKED_DEDS = 1, 2
 SYM_PACKED_40 = 1152     # doubles of a packed symmetric 40 x 40 matrix (vgpa_sym_packed_size(40))
 MAX_D = 60
 OBS_STATIC_MAX = 1 << 17
@@ -53,7 +55,7 @@ SIGNATURES = {
     "vgpa_esde_l63": _ESDE_ARGS,
     "vgpa_esde_l63_ut": _ESDE_ARGS,
     "vgpa_esde_l96_ut": _ESDE_ARGS,
-    "vgpa_esde_l96_ut_packed": [_c_int, _c_int] + [_ptr] * 4 + [_ptr, _c_int, _ptr, _c_int] + [_ptr] * 7 + [_ptr],
+    "vgpa_esde_l96_ut_packed": [_c_int, _c_int, _c_int] + [_ptr] * 4 + [_ptr, _c_int, _ptr, _c_int] + [_ptr] * 7 + [_ptr],
     "vgpa_obs_terms_packed": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
                               _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr],
     "vgpa_sym_pack": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr],

@@ -529,16 +529,18 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
     double* gv = uv + D;
     __syncthreads();
     const double theta = a.theta[(size_t)p * a.theta_stride];
-    // packed (D = 40 only): S and dEsde/dS in the layout of sym_rows.h
-    const size_t SS = a.packed ? (size_t)vgpa::SymRows40::SIZE : DD;
+    // packed (D = 40 only): S (bit 0) and dEsde/dS (bit 1) in the layout of sym_rows.h
+    const bool packed_s = (a.packed & 1) != 0, packed_g = (a.packed & 2) != 0;
+    const size_t SS = packed_s ? (size_t)vgpa::SymRows40::SIZE : DD;
+    const size_t SG = packed_g ? (size_t)vgpa::SymRows40::SIZE : DD;
     const double* Ag = a.A + e * DD;
     const double* Sg = a.S + e * SS;
     for (int q = l; q < (int)DD; q += 64) {
         const int o = (q / D) * LD + (q % D);
         Am[o] = Ag[q];
-        if (!a.packed) Sm[o] = Sg[q];
+        if (!packed_s) Sm[o] = Sg[q];
     }
-    if (a.packed) {
+    if (packed_s) {
         for (int q = l; q < (int)SS; q += 64) {
             int r, c;
             vgpa::SymRows40::coords(q, r, c);
@@ -556,7 +558,7 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
         mv[l] = m_l;
         bv[l] = a.b[e * D + l];
         sI = a.sig_inv_diag[(size_t)p * a.sig_stride + l];
-        sdiag = a.packed ? Sg[vgpa::SymRows40::row_offset(l) + l] : Sg[(size_t)l * D + l];
+        sdiag = packed_s ? Sg[vgpa::SymRows40::row_offset(l) + l] : Sg[(size_t)l * D + l];
     }
     const double nan = __builtin_nan("");
     if (!__all(sdiag > 0.0)) {
@@ -569,7 +571,7 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
             a.dEdm[e * D + l] = nan;
             if (a.dSig_t) a.dSig_t[e * D + l] = nan;
         }
-        for (int q = l; q < (int)SS; q += 64) a.dEdS[e * SS + q] = nan;
+        for (int q = l; q < (int)SG; q += 64) a.dEdS[e * SG + q] = nan;
         return;
     }
     if (act) sv[l] = sqrt(sdiag);
@@ -654,13 +656,13 @@ __device__ void l96_fallback_step(const EsdeArgs& a, size_t e, double* lds) {
     // The pivoted inverse is symmetric to rounding only; the lower triangle is computed and
     // mirrored, so that dEsde/dS is exactly symmetric like the output of the regular steps
     // (the backward scan's one-product form relies on that).
-    double* G = a.dEdS + e * SS;
+    double* G = a.dEdS + e * SG;
     for (int i = 0; i < D; ++i) {
         if (act && l <= i) {
             double s = 0.0;
             for (int k = 0; k < D; ++k) s = fma(Si[i * LD + k] * gv[k], Si[k * LD + l], s);
             const double v = 0.25 * w1 * s - 0.5 * Esde * Si[i * LD + l];
-            if (a.packed) {
+            if (packed_g) {
                 G[vgpa::SymRows40::row_offset(i) + l] = v;
                 if (vgpa::SymRows40::kept(l, i)) G[vgpa::SymRows40::row_offset(l) + i] = v;   // same diagonal block
             } else {
@@ -962,21 +964,24 @@ extern "C" int vgpa_esde(int system, int P, int N, int D, const double* A, const
 }
 
 /*
- * The Lorenz-96 unscented energy kernel at D = 40 on packed symmetric matrices (sym_rows.h): S is
- * read and dEsde_dS written with 1152 doubles a step.  Everything else as vgpa_esde_l96_ut without Edf.
+ * The Lorenz-96 unscented energy kernel at D = 40 with S and / or dEsde_dS in the packed symmetric layout
+ * (sym_rows.h): `layout` bit 0 (VGPA_PACKED_S): S is (P,N,1152); bit 1 (VGPA_PACKED_DEDS): dEsde_dS is
+ * (P,N,1152).  Everything else as vgpa_esde_l96_ut without Edf.
  */
-extern "C" int vgpa_esde_l96_ut_packed(int P, int N, const double* A, const double* b, const double* m,
-                                       const double* S_packed, const double* sig_inv_diag, int sig_stride,
+extern "C" int vgpa_esde_l96_ut_packed(int P, int N, int layout, const double* A, const double* b, const double* m,
+                                       const double* S, const double* sig_inv_diag, int sig_stride,
                                        const double* theta, int theta_stride, double* Esde_t, double* Ef,
-                                       double* dEsde_dm, double* dEsde_dS_packed, double* dth_t, double* dSig_t,
+                                       double* dEsde_dm, double* dEsde_dS, double* dth_t, double* dSig_t,
                                        int* status, void* stream) {
     VGPA_REQUIRE(P >= 0 && N >= 1, "vgpa_esde_l96_ut_packed: bad sizes P=%d N=%d", P, N);
-    VGPA_REQUIRE(A && b && m && S_packed && sig_inv_diag && theta && Esde_t && Ef && dEsde_dm && dEsde_dS_packed,
+    VGPA_REQUIRE(layout >= 0 && layout <= 3, "vgpa_esde_l96_ut_packed: layout %d is not a combination of VGPA_PACKED_S and "
+                 "VGPA_PACKED_DEDS", layout);
+    VGPA_REQUIRE(A && b && m && S && sig_inv_diag && theta && Esde_t && Ef && dEsde_dm && dEsde_dS,
                  "vgpa_esde_l96_ut_packed: null pointer argument");
     VGPA_REQUIRE((size_t)P * N < 0x7fffffffull, "vgpa_esde_l96_ut_packed: P*N too large");
-    EsdeArgs a{P, N, 40, A, b, m, S_packed, sig_inv_diag, sig_stride, theta, theta_stride,
-               Esde_t, Ef, nullptr, dEsde_dm, dEsde_dS_packed, dth_t, dSig_t, status};
-    a.packed = 1;
+    EsdeArgs a{P, N, 40, A, b, m, S, sig_inv_diag, sig_stride, theta, theta_stride,
+               Esde_t, Ef, nullptr, dEsde_dm, dEsde_dS, dth_t, dSig_t, status};
+    a.packed = layout;
     return launch_esde(VGPA_SYS_L96_UT, a, vgpa::as_stream(stream));
 }
 

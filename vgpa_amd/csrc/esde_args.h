@@ -14,7 +14,7 @@ struct EsdeArgs {
     int theta_stride;
     double *Esde_t, *Ef, *Edf, *dEdm, *dEdS, *dth_t, *dSig_t;
     int* status;
-    int packed = 0;     // Lorenz-96, D = 40 only: S and dEdS in the packed symmetric layout of sym_rows.h
+    int packed = 0;     // Lorenz-96, D = 40 only, layout of sym_rows.h: bit 0 = S is packed, bit 1 = dEdS is packed
 };
 
 // Lorenz-96, D = 40: the wavefront-per-step kernel (esde_l96_wave.hip, a translation unit of its own

@@ -272,14 +272,15 @@ __device__ __forceinline__ void wv_ring(int l, int& f1, int& b1, int& b2) {
     b2 = (l <= 1) ? l + L96Wave::D - 2 : l - 2;
 }
 
-// PACKED: S(t) is read and dEsde/dS(t) is written in the packed symmetric layout of sym_rows.h
+// PACKED_S / PACKED_G: S(t) is read / dEsde/dS(t) is written in the packed symmetric layout of sym_rows.h
 // (1152 doubles a step).  The kernel only ever reads the lower block triangle of S with whole
 // diagonal blocks, which is what that layout holds, and forms only those tiles of dEsde/dS.
-template <bool HYPER, bool PACKED>
+template <bool HYPER, bool PACKED_S, bool PACKED_G>
 __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) {
     using C = L96Wave;
     constexpr int D = C::D, LD = C::LD, DD = C::DD, VL = C::VL;
-    constexpr int SS = PACKED ? vgpa::SymRows40::SIZE : DD;      // doubles per symmetric matrix in memory
+    constexpr int SS = PACKED_S ? vgpa::SymRows40::SIZE : DD;    // doubles per S(t) in memory
+    constexpr int SG = PACKED_G ? vgpa::SymRows40::SIZE : DD;    // doubles per dEsde/dS(t) in memory
     extern __shared__ double lds_all[];
     // Two wavefronts, two consecutive steps, each with its own LDS image.  They only meet at the three
     // diagonal blocks of the factorisation, which ONE of them factors for both (the halves of that
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
     // Sixteen-byte pieces: instruction i moves rows 3 i .. 3 i + 2, lane l (< 60) the piece
     // (row 3 i + l / 20, column pair l % 20); every address is one per-lane base plus a
     // compile-time offset.  Lanes 60..63 repeat lane 59.
-    if constexpr (PACKED) {
+    if constexpr (PACKED_S) {
         // nine instructions: rows 0..15 eight at a time (8 pieces a row), rows 16..31 four at a time
         // (16 pieces), rows 32..39 three at a time on 60 lanes (20 pieces without the padding); the last
         // one has rows 38, 39 only and the lanes of its third row repeat row 39
@@ -405,8 +406,8 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
         int f1, b1, b2;
         wv_ring(l, f1, b1, b2);
         // packed: entries above the block diagonal are not in LDS, their mirror images are
-        const int r1 = PACKED ? max(f1, b1) : f1, c1 = PACKED ? min(f1, b1) : b1;
-        const int r2 = PACKED ? max(b2, b1) : b2, c2i = PACKED ? min(b2, b1) : b1;
+        const int r1 = PACKED_S ? max(f1, b1) : f1, c1 = PACKED_S ? min(f1, b1) : b1;
+        const int r2 = PACKED_S ? max(b2, b1) : b2, c2i = PACKED_S ? min(b2, b1) : b1;
         Cxx = (buf[r1 * LD + c1] - buf[r2 * LD + c2i]) * (1.0 / c2);
     }
     wave_lds_fence();
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             a.dEdm[e * D + lane] = nan;
             if (a.dSig_t) a.dSig_t[e * D + lane] = nan;
         }
-        for (int q = lane; q < SS; q += 64) a.dEdS[e * SS + q] = nan;
+        for (int q = lane; q < SG; q += 64) a.dEdS[e * SG + q] = nan;
         return;
     }
 
@@ -913,8 +914,8 @@ __global__ void __launch_bounds__(128, 2) esde_l96_ut_wave40_kernel(EsdeArgs a) 
             if (g4 == 0 && 16 * t + pi < D) a.dEdm[e * D + 16 * t + pi] = 0.5 * w1 * c2 * y;
         }
     WV_STAMP(25);
-        double* Gd = a.dEdS + e * SS;
-        if constexpr (PACKED) {
+        double* Gd = a.dEdS + e * SG;
+        if constexpr (PACKED_G) {
             // Row 16 i + x of the packed layout starts at base_i + width_i x.  Diagonal tiles go out
             // transposed like below (four consecutive doubles of row 16 i + c16); a tile below the diagonal
             // is stored once, as the rows it is: four 8-byte stores, each a full 128-byte line per

@@ -36,7 +36,8 @@ void vgpa::launch_esde_l96_wave40(const EsdeArgs& a, hipStream_t st) {
 #else
     const size_t lds = L96Wave::WG_LDS_BYTES;
 #endif
-    const size_t N = (size_t)a.N, D = 40, DD = 1600, SS = a.packed ? vgpa::SymRows40::SIZE : DD;
+    const size_t N = (size_t)a.N, D = 40, DD = 1600;
+    const size_t SS = (a.packed & 1) ? vgpa::SymRows40::SIZE : DD, SG = (a.packed & 2) ? vgpa::SymRows40::SIZE : DD;
     for (int p0 = 0; p0 < a.P; p0 += MAXP) {
         EsdeArgs s = a;
         s.P = a.P - p0 < MAXP ? a.P - p0 : MAXP;
@@ -44,18 +45,19 @@ void vgpa::launch_esde_l96_wave40(const EsdeArgs& a, hipStream_t st) {
         s.A += o * DD; s.b += o * D; s.m += o * D; s.S += o * SS;
         s.sig_inv_diag += (size_t)p0 * a.sig_stride;
         s.theta += (size_t)p0 * a.theta_stride;
-        s.Esde_t += o; s.Ef += o * D; s.dEdm += o * D; s.dEdS += o * SS;
+        s.Esde_t += o; s.Ef += o * D; s.dEdm += o * D; s.dEdS += o * SG;
         if (s.Edf) s.Edf += o * DD;
         if (s.dth_t) s.dth_t += o * D;
         if (s.dSig_t) s.dSig_t += o * D;
         if (s.status) s.status += o;
         const dim3 grid((unsigned)((s.N + 1) / 2), (unsigned)s.P);      // two steps per workgroup
-        if (s.packed) {
-            if (s.dSig_t) hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<true, true>), grid, dim3(128), lds, st, s);
-            else hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<false, true>), grid, dim3(128), lds, st, s);
-        } else {
-            if (s.dSig_t) hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<true, false>), grid, dim3(128), lds, st, s);
-            else hipLaunchKernelGGL((esde_l96_ut_wave40_kernel<false, false>), grid, dim3(128), lds, st, s);
+        auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(128), lds, st, s); };
+        const bool hyper = s.dSig_t != nullptr;
+        switch (s.packed & 3) {
+            case 3: hyper ? launch(esde_l96_ut_wave40_kernel<true, true, true>) : launch(esde_l96_ut_wave40_kernel<false, true, true>); break;
+            case 2: hyper ? launch(esde_l96_ut_wave40_kernel<true, false, true>) : launch(esde_l96_ut_wave40_kernel<false, false, true>); break;
+            case 1: hyper ? launch(esde_l96_ut_wave40_kernel<true, true, false>) : launch(esde_l96_ut_wave40_kernel<false, true, false>); break;
+            default: hyper ? launch(esde_l96_ut_wave40_kernel<true, false, false>) : launch(esde_l96_ut_wave40_kernel<false, false, false>); break;
         }
     }
 }

@@ -1038,10 +1038,10 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
                  "vgpa_bwd_scan_grad: null pointer argument");
     const bool fused = vgpa_bwd_scan_grad_is_fused(method, P, D, scan_flags, grad_flags, dEobs_dS != nullptr,
                                                    Edf != nullptr, edf_system) != 0;
-    const bool packed = (scan_flags & VGPA_SCAN_PACKED) != 0;
-    if (packed && !(fused && method == VGPA_EULER))
-        return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan_grad: VGPA_SCAN_PACKED is accepted only with the Euler method "
-                          "where vgpa_bwd_scan_grad_is_fused() holds");
+    const bool packed = (scan_flags & VGPA_SCAN_PACKED) != 0, packed_g = (scan_flags & VGPA_SCAN_PACKED_DEDS) != 0;
+    if ((packed || packed_g) && !(fused && method == VGPA_EULER))
+        return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan_grad: VGPA_SCAN_PACKED / VGPA_SCAN_PACKED_DEDS are accepted only "
+                          "with the Euler method where vgpa_bwd_scan_grad_is_fused() holds");
     if (!fused && (scan_flags & VGPA_SCAN_PSI_ROW0))
         return vgpa::fail(VGPA_EUNSUPPORTED, "vgpa_bwd_scan_grad: VGPA_SCAN_PSI_ROW0 is accepted only where "
                           "vgpa_bwd_scan_grad_is_fused() holds (the assembly kernel needs every row of Psi)");
@@ -1081,8 +1081,9 @@ extern "C" int vgpa_bwd_scan_grad(int method, int P, int N, int D, const double*
                            dEobs_dm, obs_flag, jumpS, jumpS_stride, Ef, SigInv, sig_stride, dt, lam_last, Psi_last, lam_out,
                            Psi_out, psi_all, gLA, gLb);
     };
-    if (packed) launch(bwd_grad_euler_sym_mfma40_kernel<true>);
-    else launch(bwd_grad_euler_sym_mfma40_kernel<false>);
+    if (packed) launch(bwd_grad_euler_sym_mfma40_kernel<true, true, true>);
+    else if (packed_g) launch(bwd_grad_euler_sym_mfma40_kernel<false, true, false>);
+    else launch(bwd_grad_euler_sym_mfma40_kernel<false, false, false>);
     if (g_lds_refused) return vgpa::fail(VGPA_ELAUNCH, "vgpa_bwd_scan_grad: the LDS size this launch needs was refused");
     return vgpa::check_launch("vgpa_bwd_scan_grad");
 }

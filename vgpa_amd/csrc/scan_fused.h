@@ -120,9 +120,9 @@ struct M40Third {
     }
 };
 
-// PACKED: S, dEsde_dS and Psi_out are in the packed symmetric layout (sym_rows.h), 1152 doubles a
+// PACKED_S, PACKED_G, PACKED_P: S, dEsde_dS, Psi_out are in the packed symmetric layout (sym_rows.h), 1152 doubles a
 // row instead of 1600; A, dL/dA and the terminal state Psi_last stay dense.
-template <bool PACKED>
+template <bool PACKED_S, bool PACKED_G, bool PACKED_P>
 __global__ void __launch_bounds__(M40F::NT, 4)
 bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const double* __restrict__ bvec,
                                  const double* __restrict__ mvec, const double* __restrict__ Smat,
@@ -147,17 +147,19 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int p = blockIdx.x;
     const double* Ap = A + (size_t)p * N * DD;
-    constexpr int SS = PACKED ? M40Packed::SIZE : DD;       // doubles per stored symmetric matrix
+    constexpr int SS = PACKED_S ? M40Packed::SIZE : DD;     // doubles per stored S(t), dEsde_dS(t), Psi(t)
+    constexpr int SG = PACKED_G ? M40Packed::SIZE : DD;
+    constexpr int SP = PACKED_P ? M40Packed::SIZE : DD;
     const double* Sp = Smat + (size_t)p * N * SS;
     const double* gm = dEdm + (size_t)p * N * D;
-    const double* gS = dEdS + (size_t)p * N * SS;
+    const double* gS = dEdS + (size_t)p * N * SG;
     const double* jmp = jm + (size_t)p * N * D;
     const double* bp = bvec + (size_t)p * N * D;
     const double* mp = mvec + (size_t)p * N * D;
     const double* efp = Efv + (size_t)p * N * D;
     double* lo = lam_out + (size_t)p * N * D;
     // psi_all == 0: Psi_out is (P, 1, D, D) and receives row 0 only
-    double* Po = Psi_out + (size_t)p * (psi_all ? N : 1) * SS;
+    double* Po = Psi_out + (size_t)p * (psi_all ? N : 1) * SP;
     double* gAo = gLA + (size_t)p * N * DD;
     double* gbo = gLb + (size_t)p * N * D;
     const int vl = min(lane, D - 1);
@@ -167,26 +169,22 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
     {
         const size_t last = (size_t)(N - 1);
         const double* A0 = Ap + last * DD;
-        const double* G0 = gS + last * SS;
+        const double* G0 = gS + last * SG;
         const double* S0 = Sp + last * SS;
-        double* P0 = Po + (psi_all ? last : 0) * SS;
+        double* P0 = Po + (psi_all ? last : 0) * SP;
         const bool store_last = psi_all || N == 1;
         for (int e = tid; e < DD; e += M40F::NT) {
             const int row = e / D, col = e % D;
             At[col * LD + row] = A0[e];
-            if (!PACKED) {
-                Gb[row * LD + col] = G0[e];
-                Sb[row * LD + col] = S0[e];
-            }
+            if (!PACKED_G) Gb[row * LD + col] = G0[e];
+            if (!PACKED_S) Sb[row * LD + col] = S0[e];
             const double pv = Psi_last ? Psi_last[(size_t)p * DD + e] : 0.0;
             Pb[row * LD + col] = pv;
-            if (!PACKED && store_last) P0[e] = pv;
+            if (!PACKED_P && store_last) P0[e] = pv;
         }
-        if (PACKED) {
-            M40Packed::load_image(G0, tid, M40F::NT, Gb);
-            M40Packed::load_image(S0, tid, M40F::NT, Sb);
-            if (store_last) M40Packed::pack_dense(Psi_last ? Psi_last + (size_t)p * DD : nullptr, tid, M40F::NT, P0);
-        }
+        if (PACKED_G) M40Packed::load_image(G0, tid, M40F::NT, Gb);
+        if (PACKED_S) M40Packed::load_image(S0, tid, M40F::NT, Sb);
+        if (PACKED_P && store_last) M40Packed::pack_dense(Psi_last ? Psi_last + (size_t)p * DD : nullptr, tid, M40F::NT, P0);
         if (tid < 48) mx[tid] = mp[last * D + (tid + D - 2) % D];
         if (tid >= 64 && tid < 64 + D) siv[tid - 64] = SigInv[(size_t)p * sig_stride + (size_t)(tid - 64) * (D + 1)];
     }
@@ -255,7 +253,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
             __syncthreads();                   // Psi[t], A[t]', lam[t] are in LDS
             M40F_STAMP(0);
             if (t < N - 1 && (psi_all || t == 0)) {
-                if (PACKED) M40Packed(lane).write_out(Pb, Po + (size_t)t * SS);
+                if (PACKED_P) M40Packed(lane).write_out(Pb, Po + (size_t)t * SP);
                 else M40Rows::write_out(Pb, lane, Po + (size_t)t * DD);
             }
             double lnew = 0.0;
@@ -295,8 +293,8 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
         // columns of row i of <df/dx> that are not zero: i, i + 1, i - 1, i - 2 on the ring
         const int jf1 = (i + 1) % D, jb1 = (i + D - 1) % D, jb2 = (i + D - 2) % D;
         // the three gradient wavefronts stage S(t) themselves, a third each, one row ahead
-        double preS[PACKED ? 6 : 2 * M40Third::NQ];
-        if constexpr (PACKED) M40Packed(lane).fetch_third(Sp + (size_t)(N > 1 ? N - 2 : 0) * SS, r, preS);
+        double preS[PACKED_S ? 6 : 2 * M40Third::NQ];
+        if constexpr (PACKED_S) M40Packed(lane).fetch_third(Sp + (size_t)(N > 1 ? N - 2 : 0) * SS, r, preS);
         else M40Third::fetch(Sp + (size_t)(N > 1 ? N - 2 : 0) * DD, r, lane, preS);
 #pragma unroll 1
         for (int t = N - 1; t >= 0; --t) {
@@ -343,7 +341,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
             __syncthreads();                   // the LDS images of row t are no longer read; s1 + s2 is in LDS
             M40F_STAMP(2);
             if (t >= 1) {
-                if constexpr (PACKED) {
+                if constexpr (PACKED_S) {
                     const M40Packed K(lane);
                     K.commit_third(preS, r, Sb);
                     M40F_STAMP(4);
@@ -367,9 +365,9 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
         }
     } else {
         // ---- second memory wavefront: dEsde_dS, m, <f>, b in; dL/db and s1 + s2 -------------------
-        double preG[2 * (PACKED ? M40Packed::NQ : M40Rows::NQ)];
+        double preG[2 * (PACKED_G ? M40Packed::NQ : M40Rows::NQ)];
         const int r1 = N > 1 ? N - 2 : 0;
-        if constexpr (PACKED) M40Packed(lane).fetch(gS + (size_t)r1 * SS, preG);
+        if constexpr (PACKED_G) M40Packed(lane).fetch(gS + (size_t)r1 * SG, preG);
         else M40Rows::fetch(gS + (size_t)r1 * DD, lane, preG);
         double ef_cur = efp[(size_t)(N - 1) * D + vl], b_cur = bp[(size_t)(N - 1) * D + vl];
         double ef_nxt = efp[(size_t)r1 * D + vl], b_nxt = bp[(size_t)r1 * D + vl];
@@ -403,7 +401,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
             __syncthreads();                   // S[t], m[t] no longer read
             M40F_STAMP(2);
             if (t >= 1) {
-                if constexpr (PACKED) M40Packed(lane).commit<true>(preG, Gb);
+                if constexpr (PACKED_G) M40Packed(lane).commit<true>(preG, Gb);
                 else M40Rows::commit<false>(preG, lane, Gb);
                 M40F_STAMP(4);
                 if (lane < 48) mx[lane] = m_nxt;
@@ -411,7 +409,7 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                 ef_cur = ef_nxt;
                 b_cur = b_nxt;
                 const int tp = (t >= 2) ? t - 2 : 0;
-                if constexpr (PACKED) M40Packed(lane).fetch(gS + (size_t)tp * SS, preG);
+                if constexpr (PACKED_G) M40Packed(lane).fetch(gS + (size_t)tp * SG, preG);
                 else M40Rows::fetch(gS + (size_t)tp * DD, lane, preG);
                 ef_nxt = efp[(size_t)tp * D + vl];
                 b_nxt = bp[(size_t)tp * D + vl];

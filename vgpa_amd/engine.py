@@ -332,7 +332,8 @@ def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, d
     Psi(0) and the other rows are never written; elsewhere the argument changes nothing.
 
     ``packed``: S and dEdS are given, and Psi comes back, in the packed symmetric layout
-    ((P, N, 1152), see ``sym_pack``); only where the one-kernel Euler path runs, anything else raises."""
+    ((P, N, 1152), see ``sym_pack``); only where the one-kernel Euler path runs, anything else raises.
+    ``packed="dEdS"``: dEdS alone is packed, S and Psi are dense."""
     P, N, D = prob.P, prob.N, prob.D
     lam = torch.empty_like(dEdm)
     sflags = (_lib.SCAN_SYMMETRIC if (symmetric and D > 1) else 0) | \
@@ -341,11 +342,15 @@ def bwd_scan_grad(prob, A, b, m, S, dEdm, dEdS, dEobs_dm, Ef, Edf, jumpS=None, d
     if not costate and _lib.lib.vgpa_bwd_scan_grad_is_fused(prob.method, P, D, sflags, gflags, int(dEobs_dS is not None),
                                                            int(Edf is not None), prob.system):
         sflags |= _lib.SCAN_PSI_ROW0
-        Psi = torch.empty((P, 1, _lib.SYM_PACKED_40) if packed else (P, 1, D, D), dtype=F64, device=dEdS.device)
+        Psi = torch.empty((P, 1, _lib.SYM_PACKED_40) if packed is True else (P, 1, D, D), dtype=F64, device=dEdS.device)
     else:
-        Psi = torch.empty_like(dEdS)
-    if packed:
+        Psi = torch.empty_like(S)
+    if packed is True:
         sflags |= _lib.SCAN_PACKED
+    elif packed == "dEdS":
+        sflags |= _lib.SCAN_PACKED_DEDS
+    elif packed:
+        raise ValueError("bwd_scan_grad: packed is False, True or 'dEdS'")
     if out is None:
         gLA, gLb = torch.empty_like(A), torch.empty_like(b)
     else:
@@ -393,23 +398,26 @@ def esde(system, A, b, m, S, sig_inv_diag, theta, want_edf=True, want_hyper=True
     return out
 
 
-def esde_l96_packed(A, b, m, S, sig_inv_diag, theta, want_hyper=True):
-    """vgpa_esde_l96_ut_packed -> the dict of ``esde`` with dEdS (P,N,1152) and no Edf; S is (P,N,1152)."""
+def esde_l96_packed(A, b, m, S, sig_inv_diag, theta, want_hyper=True, packed_S=True):
+    """vgpa_esde_l96_ut_packed -> the dict of ``esde`` with dEdS (P,N,1152) and no Edf; S is (P,N,1152),
+    or dense (P,N,40,40) with ``packed_S=False``."""
     P, N, D = A.shape[0], A.shape[1], A.shape[-1]
-    if D != 40 or S.shape != (P, N, _lib.SYM_PACKED_40):
-        raise ValueError("esde_l96_packed: needs D == 40 and S of shape (P, N, %d)" % _lib.SYM_PACKED_40)
+    if D != 40 or S.shape != ((P, N, _lib.SYM_PACKED_40) if packed_S else (P, N, D, D)):
+        raise ValueError("esde_l96_packed: needs D == 40 and S of shape (P, N, %d), or (P, N, 40, 40) with packed_S=False"
+                         % _lib.SYM_PACKED_40)
     dev = A.device
     out = dict(
         Esde_t=torch.empty((P, N), dtype=F64, device=dev),
         Ef=torch.empty((P, N, D), dtype=F64, device=dev),
         Edf=None,
         dEdm=torch.empty((P, N, D), dtype=F64, device=dev),
-        dEdS=torch.empty_like(S),
+        dEdS=torch.empty((P, N, _lib.SYM_PACKED_40), dtype=F64, device=dev),
         dth_t=torch.empty((P, N, D), dtype=F64, device=dev) if want_hyper else None,
         dSig_t=torch.empty((P, N, D), dtype=F64, device=dev) if want_hyper else None,
         status=torch.zeros((P, N), dtype=torch.int32, device=dev),
     )
-    call("vgpa_esde_l96_ut_packed", P, N, _p(A), _p(b), _p(m), _p(S), _p(sig_inv_diag), _par_stride(sig_inv_diag, P, D),
+    layout = _lib.PACKED_DEDS | (_lib.PACKED_S if packed_S else 0)
+    call("vgpa_esde_l96_ut_packed", P, N, layout, _p(A), _p(b), _p(m), _p(S), _p(sig_inv_diag), _par_stride(sig_inv_diag, P, D),
          _p(theta), _par_stride(theta, P, 1), _p(out["Esde_t"]), _p(out["Ef"]), _p(out["dEdm"]), _p(out["dEdS"]),
          _p(out["dth_t"]), _p(out["dSig_t"]), _p(out["status"]), _stream())
     return out
@@ -558,7 +566,7 @@ def energy_terms(system, A, b, m, S, SigInv, sig_inv_diag, theta, w, dt, want_hy
     if packed:
         if system != _lib.SYS_L96_UT or want_edf:
             raise ValueError("energy_terms: packed matrices need the Lorenz-96 system and want_edf=False")
-        out = esde_l96_packed(A, b, m, S, sig_inv_diag, theta, want_hyper)
+        out = esde_l96_packed(A, b, m, S, sig_inv_diag, theta, want_hyper, packed_S=(packed is True))
     else:
         out = esde(system, A, b, m, S, sig_inv_diag, theta, want_edf, want_hyper)
     out["Esde"] = reduce_energy(out["Esde_t"], w, dt)
@@ -673,8 +681,10 @@ def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer
     ``packed=True`` (only where ``packed_supported(prob)``): the symmetric matrices of every time row
     -- State.S, State.dEdS, State.Psi -- are kept as (P, N, 1152) in the packed layout of ``sym_pack``
     instead of (P, N, 40, 40); ``sym_unpack`` expands them.  F, the gradient and every vector are the
-    same as without it (the energy kernel bit for bit, the scans to rounding: same products, same
-    order); the evaluation moves 16 % fewer bytes.  State.Edf is None."""
+    same as without it, bit for bit (same products, same order); the evaluation moves 16 % fewer bytes.
+    State.Edf is None.  ``packed="dEdS"``: only State.dEdS is packed -- it is an intermediate between the
+    energy kernel and the backward scan, not one of the arrays the reference publishes -- and S, Psi are
+    the dense arrays of the contract."""
     if packed and (prob.system < 0 or want_edf or not packed_supported(prob, outer)):
         raise ValueError("free_energy_and_gradient: packed=True needs the Lorenz-96 D = 40 Euler problem with diagonal "
                          "noise, more than 160 problems, and want_edf=False (see packed_supported)")
@@ -682,8 +692,10 @@ def free_energy_and_gradient(prob, A, b, want_hyper=False, want_edf=False, outer
         st = free_energy(prob, A, b, want_hyper=want_hyper, want_edf=True)
         gLA, gLb = gradient(prob, A, b, st, outer=outer, out=out)
         return st, gLA, gLb
-    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd, packed=packed)
-    Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S, packed=packed)
+    if packed not in (False, True, "dEdS"):
+        raise ValueError("free_energy_and_gradient: packed is False, True or 'dEdS'")
+    m, S = fwd_scan(prob.method, A, b, prob.m0, prob.S0, prob.Sigma, prob.dt, symmetric=prob.sym_fwd, packed=(packed is True))
+    Eobs, dEobs_dm, jumpS = obs_terms(prob, m, S, packed=(packed is True))
     implicit_ok = prob.D > 1 and prob.system in (_lib.SYS_L96_UT, _lib.SYS_L63, _lib.SYS_L63_UT)
     en = energy_terms(prob.system, A, b, m, S, prob.SigInv, prob.sig_inv_diag, prob.theta, prob.w, prob.dt,
                       want_hyper, want_edf=want_edf or not implicit_ok, packed=packed)
