@@ -32,7 +32,8 @@ struct M40F {
     static constexpr int OFF_MX = OFF_LAM + D;      // m(t) on the ring: mx[k] = m[(k - 2) mod D], k = 0 .. 47
     static constexpr int OFF_SI = OFF_MX + 48;      // diagonal of SigInv
     static constexpr int OFF_SC = OFF_SI + D;       // s1 + s2 of the current row
-    static constexpr int LDS_DOUBLES = OFF_SC + 2;
+    static constexpr int OFF_S2 = OFF_SC + 2;       // the second image of S: rows alternate between the two
+    static constexpr int LDS_DOUBLES = OFF_S2 + MS; // 81 680 bytes: two workgroups fill the 160 KB of a compute unit
 };
 
 // One wavefront's traffic for a whole 40 x 40 matrix in 16-byte pieces, three matrix rows per
@@ -296,9 +297,16 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
         double preS[PACKED_S ? 6 : 2 * M40Third::NQ];
         if constexpr (PACKED_S) M40Packed(lane).fetch_third(Sp + (size_t)(N > 1 ? N - 2 : 0) * SS, r, preS);
         else M40Third::fetch(Sp + (size_t)(N > 1 ? N - 2 : 0) * DD, r, lane, preS);
+        // S(t) has two LDS images that take turns: the products of row t read one of them AFTER the second barrier
+        // of the step, while the row for the next step is committed to the other.  Between the barriers these
+        // wavefronts only collect their left operand from the images that are rewritten afterwards (A', Psi, m): the
+        // matrix cores are then theirs while the recurrence's wavefronts update Psi, instead of being shared with
+        // them before the barrier.
+        double* Scur = Sb;
+        double* Snext = lds + M40F::OFF_S2;
 #pragma unroll 1
         for (int t = N - 1; t >= 0; --t) {
-            __syncthreads();                   // row t: A', Psi, S, m are in LDS
+            __syncthreads();                   // row t: A', Psi, m are in LDS (and S, in its own image)
             M40F_STAMP(0);
             double x[10];
             mfma_f64x4 z[3];
@@ -322,9 +330,14 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                         x[kk] = si * (ed + av) - 2.0 * (u ? pv.y : pv.x);
                     }
                 }
+            }
+            M40F_STAMP(1);
+            __syncthreads();                   // the LDS images of row t (but S) are no longer read; s1 + s2 is in LDS
+            M40F_STAMP(2);
+            {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const double* srow = Sb + min(16 * c + q, D - 1) * LD + k0;
+                    const double* srow = Scur + min(16 * c + q, D - 1) * LD + k0;
                     double sb[10];
 #pragma unroll
                     for (int h = 0; h < 5; ++h) {
@@ -337,20 +350,24 @@ bwd_grad_euler_sym_mfma40_kernel(int N, const double* __restrict__ A, const doub
                     for (int k = 0; k < 10; ++k) z[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[k], sb[k], z[c], 0, 0, 0);
                 }
             }
-            M40F_STAMP(1);
-            __syncthreads();                   // the LDS images of row t are no longer read; s1 + s2 is in LDS
-            M40F_STAMP(2);
+            // the next row of S goes to the image that nobody reads in this step (measured: committing it here, behind
+            // the products, is faster than before the second barrier)
             if (t >= 1) {
                 if constexpr (PACKED_S) {
                     const M40Packed K(lane);
-                    K.commit_third(preS, r, Sb);
+                    K.commit_third(preS, r, Snext);
                     M40F_STAMP(4);
                     K.fetch_third(Sp + (size_t)(t >= 2 ? t - 2 : 0) * SS, r, preS);
                 } else {
-                    M40Third::commit(preS, r, lane, Sb);
+                    M40Third::commit(preS, r, lane, Snext);
                     M40F_STAMP(4);
                     M40Third::fetch(Sp + (size_t)(t >= 2 ? t - 2 : 0) * DD, r, lane, preS);
                 }
+            }
+            {
+                double* tmp = Scur;
+                Scur = Snext;
+                Snext = tmp;
             }
             const double s12 = sc[0];
             double* out = gAo + (size_t)t * DD;
